@@ -1,0 +1,108 @@
+"""The CPU restatement (oracle/demod_oracle.c) against the golden vectors that
+the compiled reference produced (tests/golden/make_golden.py), and -- where
+oracle/_ref is present -- against the reference's own functions directly.
+Bit-exact: the restatement keeps the reference's float operation order."""
+import numpy as np
+import pytest
+
+import oracle
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return oracle.restatement()
+
+
+def test_sos_tables_hex_exact(orc, manifest):
+    for row in manifest["sos"]:
+        sos = orc.design_sos(row["kind"], row["degree"], row["fc"], row["fs"], row["epsilon"])
+        want = np.array([[float.fromhex(v) for v in r] for r in row["sos_hex"]], dtype=np.float32)
+        assert np.array_equal(bits(sos), bits(want)), row
+
+
+def test_sos_survey_table(orc):
+    # SURVEY.md Appendix A.5, fc/fs = 12500/125000, Butterworth degree 3
+    sos = orc.design_sos(0, 3, 12500.0, 125000.0)
+    assert float(sos[0, 4]).hex() == "-0x1.4021d80000000p+0"
+    assert float(sos[0, 5]).hex() == "0x1.17690c0000000p-1"
+    assert float(sos[1, 0]).hex() == "0x1.28886e0000000p-6"
+    assert float(sos[1, 4]).hex() == "-0x1.04e0860000000p-1"
+
+
+def test_unpack_every_byte(orc, golden):
+    allbytes = np.arange(256, dtype=np.uint8)
+    got = orc.unpack_shift(allbytes)
+    assert np.array_equal(bits(got), bits(golden("unpack_shift_0_255.npy")))
+    assert got[255] == -128.0 and got[127] == 0.0 and got[0] == -127.0  # src/matrix.c:92
+    assert np.array_equal(bits(orc.unpack_normalize(allbytes)),
+                          bits(golden("unpack_normalize_0_255.npy")))
+
+
+def test_discriminator_known_answers(orc, golden):
+    quads = golden("quads_bytes.npy")
+    got = orc.discriminate(orc.unpack_shift(quads.reshape(-1)))
+    want = golden("quads_discriminator.npy")
+    assert np.array_equal(bits(got), bits(want))
+    # signed-zero / +-pi cases
+    pi = np.float32(np.pi)
+    assert got[0] == pi and got[4] == -pi and got[5] == pi and got[2] == 0 and got[6] == 0
+
+
+def test_streams_bit_exact(orc, manifest, golden):
+    for name, case in manifest["streams"].items():
+        fl = oracle.Flags(**case["flags"])
+        data = oracle.synth_bytes(case["seed"], 0, case["n_chunks"] * fl.buf_size)
+        got = orc.process(fl, data)
+        want = golden(case["file"])
+        assert got.shape == want.shape, name
+        assert np.array_equal(bits(got), bits(want)), name
+
+
+def test_fm_like_bit_exact(orc, manifest, golden):
+    data = golden(manifest["fm_like"]["input"])
+    for key in ("dsd", "multimon"):
+        c = manifest["fm_like"][key]
+        got = orc.process(oracle.Flags(**c["flags"]), data)
+        assert np.array_equal(bits(got), bits(golden(c["file"]))), key
+
+
+def test_synth_bytes_numpy_matches_c(orc):
+    for first, n in ((0, 4096), (5, 1000), (8191, 77), (1 << 33, 64)):
+        assert np.array_equal(orc.synth_bytes(0xD3300D02, first, n),
+                              oracle.synth_bytes(0xD3300D02, first, n))
+
+
+def test_chunk_parallel_equals_serial(orc):
+    fl = oracle.Flags(lowpass_in=12500.0, lowpass_out=6500.0, buf_size=4096)
+    data = oracle.synth_bytes(7, 0, 4096 * 13 + 100)
+    a = orc.process(fl, data)
+    b = orc.process(fl, data, threads=4)
+    assert a.size == 13 * 1024 + 25
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_rejects_undefined_option_sets(orc):
+    data = oracle.synth_bytes(1, 0, 4096)
+    with pytest.raises(ValueError):
+        orc.process(oracle.Flags(in_degree=3, buf_size=4096), data)      # -D without -L
+    with pytest.raises(ValueError):
+        orc.process(oracle.Flags(mode=0x14, buf_size=4096), data)        # -q1 correctIq
+
+
+def test_against_live_reference(orc):
+    ref = oracle.reference()
+    if ref is None:
+        pytest.skip("oracle/_ref not present (no /root/reference on this machine)")
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        fl = oracle.Flags(lowpass_in=float(rng.choice([0, 12500.0])),
+                          lowpass_out=float(rng.choice([6500.0, 12500.0])),
+                          out_degree=int(rng.integers(1, 9)),
+                          sample_rate=float(rng.choice([96000.0, 125000.0])),
+                          buf_size=int(1 << rng.integers(5, 14)))
+        data = rng.integers(0, 256, fl.buf_size * 3, dtype=np.uint8)
+        assert np.array_equal(bits(orc.process(fl, data)), bits(ref.process(fl, data))), fl
