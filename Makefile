@@ -1,0 +1,45 @@
+# Builds the MI355X-native demodulation library, the CLI host and the test oracle.
+#
+#   make lib      demodulator_amd/libdemod_hip.so      (HIP kernels + C ABI, gfx950)
+#   make backend  demodulator_amd/libdemod_backend.so  (processMatrix/allocateBuffer adapter)
+#   make cli      demodulator_amd/demod                (C host, reference CLI contract)
+#   make oracle   oracle/libdemod_oracle.so (+ oracle/_ref when /root/reference exists)
+#
+# Everything is built in-tree so the binaries travel to the GPU box with the
+# source snapshot.
+
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG      = demodulator_amd
+SRC      = $(PKG)/csrc
+# -ffp-contract=off: the kernels spell every fused multiply-add explicitly
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall \
+           -Wno-unused-function -Iinclude -I$(SRC)
+CFLAGS   = -O2 -std=gnu99 -Wall -Iinclude
+
+all: lib backend cli oracle
+
+lib: $(PKG)/libdemod_hip.so
+$(PKG)/libdemod_hip.so: $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/plan.cpp $(SRC)/kernels.h \
+                        $(SRC)/plan.h include/demod_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/plan.cpp
+
+backend: $(PKG)/libdemod_backend.so
+$(PKG)/libdemod_backend.so: $(SRC)/backend.c include/demod_backend.h include/demod_hip.h $(PKG)/libdemod_hip.so
+	$(CC) $(CFLAGS) -fPIC -shared -o $@ $(SRC)/backend.c -L$(PKG) -ldemod_hip \
+	    -Wl,-rpath,'$$ORIGIN' -lpthread
+
+cli: $(PKG)/demod
+$(PKG)/demod: $(SRC)/main.c include/demod_backend.h include/demod_hip.h $(PKG)/libdemod_backend.so
+	$(CC) $(CFLAGS) -o $@ $(SRC)/main.c -L$(PKG) -ldemod_backend -ldemod_hip \
+	    -Wl,-rpath,'$$ORIGIN' -lpthread -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(PKG)/libdemod_hip.so $(PKG)/libdemod_backend.so $(PKG)/demod
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib backend cli oracle clean

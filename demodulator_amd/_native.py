@@ -1,0 +1,104 @@
+"""ctypes binding of the C ABI in include/demod_hip.h (libdemod_hip.so).
+
+The library is the product: there is no Python or CPU implementation of the
+path behind it.  If it is missing, or no MI355X is visible, loading or context
+creation raises -- nothing falls back silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdemod_hip.so")
+
+ABI_VERSION = 1
+HALO_BYTES = 64
+ROW_BYTES = 1024
+
+# every symbol include/demod_hip.h declares
+EXPORTS = (
+    "demod_default_params", "demod_abi_version", "demod_create", "demod_destroy",
+    "demod_last_error", "demod_process_device", "demod_process_host", "demod_alloc_pinned",
+    "demod_free_pinned", "demod_alloc_device", "demod_free_device", "demod_copy_to_device",
+    "demod_copy_to_host", "demod_synchronize", "demod_get_sos", "demod_get_taps",
+    "demod_get_head_outputs", "demod_design_query", "demod_set_segment_rows", "demod_synth_fill",
+    "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms",
+    "demod_enable_timing",
+)
+
+
+class Params(C.Structure):
+    """struct demod_params"""
+    _fields_ = [
+        ("sample_rate", C.c_double), ("lowpass_in", C.c_double), ("lowpass_out", C.c_double),
+        ("epsilon", C.c_double), ("in_degree", C.c_uint32), ("out_degree", C.c_uint32),
+        ("mode", C.c_uint32), ("reserved", C.c_uint32), ("buf_size", C.c_uint64),
+    ]
+
+
+class Span(C.Structure):
+    """struct demod_span"""
+    _fields_ = [
+        ("chunk_offset", C.c_uint64), ("halo", C.c_void_p), ("end_of_stream", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class DemodError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libdemod_hip.so (once).  torch, when installed, is imported first so
+    that both share one HIP runtime in the process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DemodError(
+            f"{LIB_PATH} is missing: build it with `make lib` (hipcc --offload-arch=gfx950). "
+            "There is no fallback implementation of the demodulation path.")
+    try:
+        import torch  # noqa: F401  (its bundled libamdhip64 must be the one in the process)
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    sig = {
+        "demod_default_params": (None, [C.POINTER(Params)]),
+        "demod_abi_version": (i32, []),
+        "demod_create": (i32, [C.POINTER(Params), i32, C.POINTER(vp)]),
+        "demod_destroy": (None, [vp]),
+        "demod_last_error": (C.c_char_p, [vp]),
+        "demod_process_device": (i32, [vp, vp, u64, vp, C.POINTER(Span), vp]),
+        "demod_process_host": (i32, [vp, vp, u64, vp, C.POINTER(Span)]),
+        "demod_alloc_pinned": (i32, [C.POINTER(vp), C.c_size_t]),
+        "demod_free_pinned": (None, [vp]),
+        "demod_alloc_device": (i32, [vp, C.POINTER(vp), C.c_size_t]),
+        "demod_free_device": (None, [vp, vp]),
+        "demod_copy_to_device": (i32, [vp, vp, vp, C.c_size_t]),
+        "demod_copy_to_host": (i32, [vp, vp, vp, C.c_size_t]),
+        "demod_synchronize": (i32, [vp]),
+        "demod_get_sos": (i32, [vp, i32, vp, i32]),
+        "demod_get_taps": (i32, [vp, i32, vp, i32, C.POINTER(C.c_float)]),
+        "demod_get_head_outputs": (i32, [vp]),
+        "demod_design_query": (i32, [C.POINTER(Params), i32, vp, i32, vp, i32, C.POINTER(C.c_float),
+                                     C.POINTER(i32), C.POINTER(i32)]),
+        "demod_set_segment_rows": (i32, [vp, u32]),
+        "demod_synth_fill": (i32, [vp, vp, u64, u64, u64, vp]),
+        "demod_selftest_atan2": (i32, [vp, vp, vp, vp, u32]),
+        "demod_selftest_lane_shift": (i32, [vp, vp, C.c_float, vp]),
+        "demod_kernel_ms": (C.c_double, [vp, C.POINTER(i32)]),
+        "demod_enable_timing": (None, [vp, i32]),
+    }
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError here = the library does not match the header
+        fn.restype, fn.argtypes = sig[name]
+    if lib.demod_abi_version() != ABI_VERSION:
+        raise DemodError("libdemod_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,668 @@
+// api.cpp -- the C ABI declared in include/demod_hip.h: contexts, the device
+// hot-path entry point, the pinned double-buffered host path, helpers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "demod_hip.h"
+#include "kernels.h"
+#include "plan.h"
+
+using namespace demod;
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_create_error;
+
+constexpr uint64_t kStageBytes = 32ull << 20;  // host path: input bytes per staged piece
+constexpr uint32_t kTinyThreads = 8192;
+
+uint32_t log2u(uint64_t v) {
+    uint32_t l = 0;
+    while ((1ull << (l + 1)) <= v) ++l;
+    return l;
+}
+
+}  // namespace
+
+struct demod_ctx {
+    Options opt;
+    Plan plan;
+    int device = 0;
+    std::string err;
+
+    hipStream_t aux = nullptr;  // chunk-head kernel runs here, beside the streaming kernel
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    bool heads_inline = false;
+    uint32_t seg_rows = 0;  // 0 = automatic
+
+    // kernel timing (HIP events on the launch stream)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+
+    // scratch for the whole-chunk literal path (chunks < 1 KiB)
+    float *tiny_work = nullptr;
+    uint64_t tiny_stride = 0;
+
+    // host path staging: two slots, each pinned in/out + device in/out + stream
+    struct Slot {
+        void *h_in = nullptr, *h_out = nullptr, *h_halo = nullptr, *d_in = nullptr, *d_out = nullptr, *d_halo = nullptr;
+        hipStream_t stream = nullptr;
+        uint64_t out_floats = 0;  // results waiting in h_out
+        float *dst = nullptr;     // where they go
+    } slot[2];
+    bool slots_ready = false;
+
+    bool fail(int code, const char *what, hipError_t e = hipSuccess) {
+        char buf[384];
+        if (e != hipSuccess)
+            snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(buf, sizeof buf, "%s", what);
+        err = buf;
+        (void) code;
+        return false;
+    }
+};
+
+#define HIP_TRY(ctx, call)                               \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) {                          \
+            (ctx)->fail(DEMOD_E_HIP, #call, e_);         \
+            return DEMOD_E_HIP;                          \
+        }                                                \
+    } while (0)
+
+extern "C" {
+
+void demod_default_params(demod_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->sample_rate = 125000.;
+    p->lowpass_in = 0.;
+    p->lowpass_out = 12500.;
+    p->epsilon = .3;
+    p->in_degree = 0;
+    p->out_degree = 3;
+    p->mode = 0x10;
+    p->buf_size = DEMOD_DEFAULT_BUF_SIZE;
+}
+
+int demod_abi_version(void) { return DEMOD_ABI_VERSION; }
+
+const char *demod_last_error(const demod_ctx *ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> g(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_create_error;
+    return copy.c_str();
+}
+
+static int create_fail(int code, const std::string &msg) {
+    std::lock_guard<std::mutex> g(g_err_mutex);
+    g_create_error = msg;
+    return code;
+}
+
+int demod_create(const demod_params *p, int device, demod_ctx **out) {
+    if (!p || !out) return create_fail(DEMOD_E_INVAL, "null argument");
+    *out = nullptr;
+    demod_ctx *ctx = new (std::nothrow) demod_ctx;
+    if (!ctx) return create_fail(DEMOD_E_NOMEM, "out of memory");
+    ctx->opt = options_from_params(*p);
+    std::string err;
+    if (!build_plan(ctx->opt, ctx->plan, err)) {
+        delete ctx;
+        return create_fail(DEMOD_E_INVAL, err);
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        delete ctx;
+        return create_fail(DEMOD_E_NODEVICE,
+                           std::string("no HIP device: the demodulation path has no CPU fallback (") +
+                               hipGetErrorString(e) + ")");
+    }
+    if (device < 0 || device >= n_dev) {
+        delete ctx;
+        return create_fail(DEMOD_E_INVAL, "device index out of range");
+    }
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming)) != hipSuccess) {
+        std::string msg = std::string("HIP setup failed: ") + hipGetErrorString(e);
+        demod_destroy(ctx);
+        return create_fail(DEMOD_E_HIP, msg);
+    }
+    const char *inl = getenv("DEMOD_HEADS_INLINE");
+    ctx->heads_inline = inl && inl[0] == '1';
+    *out = ctx;
+    return DEMOD_OK;
+}
+
+void demod_destroy(demod_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    for (auto &s : ctx->slot) {
+        if (s.stream) (void) hipStreamSynchronize(s.stream);
+        if (s.h_in) (void) hipHostFree(s.h_in);
+        if (s.h_out) (void) hipHostFree(s.h_out);
+        if (s.h_halo) (void) hipHostFree(s.h_halo);
+        if (s.d_in) (void) hipFree(s.d_in);
+        if (s.d_out) (void) hipFree(s.d_out);
+        if (s.d_halo) (void) hipFree(s.d_halo);
+        if (s.stream) (void) hipStreamDestroy(s.stream);
+    }
+    for (auto &p : ctx->timed) {
+        (void) hipEventDestroy(p.first);
+        (void) hipEventDestroy(p.second);
+    }
+    for (auto &p : ctx->event_pool) {
+        (void) hipEventDestroy(p.first);
+        (void) hipEventDestroy(p.second);
+    }
+    if (ctx->tiny_work) (void) hipFree(ctx->tiny_work);
+    if (ctx->aux) (void) hipStreamDestroy(ctx->aux);
+    if (ctx->fork_ev) (void) hipEventDestroy(ctx->fork_ev);
+    if (ctx->join_ev) (void) hipEventDestroy(ctx->join_ev);
+    delete ctx;
+}
+
+int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (rows & (rows - 1)) {
+        ctx->fail(DEMOD_E_INVAL, "segment rows must be a power of two (or 0)");
+        return DEMOD_E_INVAL;
+    }
+    ctx->seg_rows = rows;
+    return DEMOD_OK;
+}
+
+void demod_enable_timing(demod_ctx *ctx, int on) {
+    if (ctx) ctx->timing = on != 0;
+}
+
+double demod_kernel_ms(demod_ctx *ctx, int *launches) {
+    if (launches) *launches = 0;
+    if (!ctx) return -1.0;
+    if (!ctx->timing) {
+        ctx->timing = true;
+        return -1.0;
+    }
+    if (ctx->timed.empty()) return -1.0;
+    double total = 0.0;
+    int n = 0;
+    for (auto &p : ctx->timed) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            total += ms;
+            ++n;
+        }
+        ctx->event_pool.push_back(p);
+    }
+    ctx->timed.clear();
+    if (launches) *launches = n;
+    return n ? total / n : -1.0;
+}
+
+// ---------------------------------------------------------------------------
+// the hot path on device-resident data
+// ---------------------------------------------------------------------------
+
+static void fill_stencils(const Plan &pl, RowLaunch &r) {
+    for (int j = 0; j < kMaxTaps; ++j) {
+        r.hin[j] = pl.in.h[j];
+        r.hout[j] = pl.out.h[j];
+    }
+    r.bias_im = pl.in.bias_im;
+    r.scale = (float) (2. / 255.);
+}
+
+static void fill_sections(const Plan &pl, int &sec_in, int &sec_out, float (*sos_in)[6],
+                          float (*sos_out)[6], float &scale) {
+    sec_in = pl.in.sections;
+    sec_out = pl.out.sections;
+    memcpy(sos_in, pl.in.sos, sizeof pl.in.sos);
+    memcpy(sos_out, pl.out.sos, sizeof pl.out.sos);
+    scale = (float) (2. / 255.);
+}
+
+static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, uint64_t n_chunks,
+                    uint32_t tail_bytes, float *d_out, hipStream_t stream) {
+    const Plan &pl = ctx->plan;
+    const uint64_t stride = 5 * chunk_bytes + 2 * (4 * kMaxSections + 8);
+    if (!ctx->tiny_work || ctx->tiny_stride < stride) {
+        if (ctx->tiny_work) HIP_TRY(ctx, hipFree(ctx->tiny_work));
+        ctx->tiny_work = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **) &ctx->tiny_work, (size_t) kTinyThreads * stride * sizeof(float)));
+        ctx->tiny_stride = stride;
+    }
+    TinyLaunch t{};
+    t.in = d_in;
+    t.out = d_out;
+    t.work = ctx->tiny_work;
+    t.work_stride = ctx->tiny_stride;
+    t.chunk_bytes = chunk_bytes;
+    t.n_chunks = n_chunks;
+    t.tail_bytes = tail_bytes;
+    fill_sections(pl, t.sec_in, t.sec_out, t.sos_in, t.sos_out, t.scale);
+    const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
+    const uint32_t threads = (uint32_t) std::min<uint64_t>(total, kTinyThreads);
+    if (launch_tiny(t, pl.conditioning, threads, stream)) {
+        ctx->fail(DEMOD_E_HIP, "demod_tiny launch", hipGetLastError());
+        return DEMOD_E_HIP;
+    }
+    return DEMOD_OK;
+}
+
+int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, void *d_out_v,
+                         const demod_span *span, void *stream_v) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (n_bytes == 0) return DEMOD_OK;
+    const uint8_t *d_in = static_cast<const uint8_t *>(d_in_v);
+    float *d_out = static_cast<float *>(d_out_v);
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const Plan &pl = ctx->plan;
+    const uint64_t B = pl.chunk_bytes;
+
+    if (!d_in || !d_out || (n_bytes & 3) || ((uintptr_t) d_in & 15) || ((uintptr_t) d_out & 15)) {
+        ctx->fail(DEMOD_E_INVAL, "buffers must be non-null and 16-byte aligned, n_bytes a multiple of 4");
+        return DEMOD_E_INVAL;
+    }
+    const uint64_t offset = span ? span->chunk_offset : 0;
+    const bool eos = span ? span->end_of_stream != 0 : true;
+    const uint8_t *halo = span ? static_cast<const uint8_t *>(span->halo) : nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- chunks shorter than one row: literal whole-chunk kernel ----------
+    if (B < kRowBytes) {
+        if (offset != 0) {
+            ctx->fail(DEMOD_E_INVAL, "chunk_offset must be 0 when the chunk size is below 1024 bytes");
+            return DEMOD_E_INVAL;
+        }
+        const uint64_t full = n_bytes / B;
+        const uint32_t tail = (uint32_t) (n_bytes - full * B);
+        if (tail && !eos) {
+            ctx->fail(DEMOD_E_INVAL, "buffer must hold whole chunks unless it ends the stream");
+            return DEMOD_E_INVAL;
+        }
+        return run_tiny(ctx, d_in, B, full, tail, d_out, stream);
+    }
+
+    if (offset >= B || (offset & (kRowBytes - 1))) {
+        ctx->fail(DEMOD_E_INVAL, "chunk_offset must be a multiple of 1024 below the chunk size");
+        return DEMOD_E_INVAL;
+    }
+    const uint64_t end_in_chunk = (offset + n_bytes) % B;  // 0: buffer ends on a chunk boundary
+    if (end_in_chunk != 0 && !eos && !halo) {
+        ctx->fail(DEMOD_E_INVAL, "buffer ends inside a chunk of a continuing stream: span.halo is required");
+        return DEMOD_E_INVAL;
+    }
+    if ((n_bytes & (kRowBytes - 1)) && !eos) {
+        ctx->fail(DEMOD_E_INVAL, "a continuing stream must be cut at multiples of 1024 bytes");
+        return DEMOD_E_INVAL;
+    }
+    if (offset + n_bytes > (uint64_t) 0xFFFFFFFFu * kRowBytes) {
+        ctx->fail(DEMOD_E_INVAL, "buffer too large for one call (limit 4 TiB)");
+        return DEMOD_E_INVAL;
+    }
+
+    // A final short chunk of less than one row (it then starts inside this
+    // buffer, at a row boundary) goes to the literal kernel; the rest is rows.
+    uint64_t row_bytes = n_bytes;
+    uint32_t tiny_tail = 0;
+    if (eos && end_in_chunk != 0 && end_in_chunk < kRowBytes && end_in_chunk <= n_bytes) {
+        tiny_tail = (uint32_t) end_in_chunk;
+        row_bytes = n_bytes - end_in_chunk;
+    }
+
+    const uint32_t rpc_log2 = log2u(B / kRowBytes);
+    uint32_t seg_log2 = ctx->seg_rows ? log2u(ctx->seg_rows) : 5u;
+    seg_log2 = std::min(seg_log2, rpc_log2);
+
+    // ---- chunk heads (literal replay), beside the streaming kernel --------
+    const uint64_t first_head = offset == 0 ? 0 : B - offset;
+    uint32_t n_heads = 0;
+    if (first_head < row_bytes) n_heads = (uint32_t) ((row_bytes - first_head + B - 1) / B);
+    hipStream_t head_stream = stream;
+    const bool forked = n_heads && pl.head_quads && !ctx->heads_inline;
+    if (n_heads && pl.head_quads) {
+        HeadLaunch h{};
+        h.in = d_in + first_head;
+        h.out = d_out + first_head / 4;
+        h.chunk_bytes = B;
+        h.n_heads = n_heads;
+        h.head_outputs = 4u * (uint32_t) pl.head_quads;
+        const uint64_t last_len = row_bytes - (first_head + (uint64_t) (n_heads - 1) * B);
+        // a last chunk that continues past the buffer is a full chunk for the
+        // head window; only a stream end makes it short
+        h.last_chunk_bytes = (uint32_t) ((eos && last_len < B) ? last_len : B);
+        fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale);
+        if (forked) {
+            HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fork_ev, 0));
+            head_stream = ctx->aux;
+        }
+        if (launch_heads(h, pl.conditioning, head_stream)) {
+            ctx->fail(DEMOD_E_HIP, "demod_heads launch", hipGetLastError());
+            return DEMOD_E_HIP;
+        }
+        if (forked) HIP_TRY(ctx, hipEventRecord(ctx->join_ev, ctx->aux));
+    }
+
+    // ---- the fused streaming kernel ---------------------------------------
+    if (row_bytes) {
+        RowLaunch r{};
+        r.in = d_in;
+        r.out = d_out;
+        r.halo = (!eos && end_in_chunk != 0) ? halo : nullptr;
+        r.phase_rows = (uint32_t) (offset / kRowBytes);
+        r.rpc_log2 = rpc_log2;
+        r.seg_log2 = seg_log2;
+        r.head_quads = (uint32_t) pl.head_quads;
+        fill_stencils(pl, r);
+
+        const uint32_t ragged = (uint32_t) (row_bytes & (kRowBytes - 1));
+        const uint32_t total_rows = (uint32_t) ((row_bytes + kRowBytes - 1) / kRowBytes);
+        // rows of the final short chunk (the only place a ragged row can be)
+        // run as their own launch of the bounds-checked build
+        uint32_t split = total_rows;
+        if (ragged) {
+            const uint64_t last_chunk_start = row_bytes - std::min<uint64_t>(end_in_chunk, row_bytes);
+            split = (uint32_t) (last_chunk_start / kRowBytes);
+        }
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        if (ctx->timing) {
+            if (!ctx->event_pool.empty()) {
+                ev = ctx->event_pool.back();
+                ctx->event_pool.pop_back();
+            } else {
+                HIP_TRY(ctx, hipEventCreate(&ev.first));
+                HIP_TRY(ctx, hipEventCreate(&ev.second));
+            }
+            HIP_TRY(ctx, hipEventRecord(ev.first, stream));
+        }
+        if (split) {
+            RowLaunch a = r;
+            a.n_rows = split;
+            a.ragged_bytes = 0;
+            if (ragged) a.halo = nullptr;
+            if (launch_rows(a, pl.in.taps, pl.out.taps, pl.conditioning, stream)) {
+                ctx->fail(DEMOD_E_HIP, "demod_rows launch", hipGetLastError());
+                return DEMOD_E_HIP;
+            }
+        }
+        if (ragged) {
+            RowLaunch a = r;
+            a.in = d_in + (uint64_t) split * kRowBytes;
+            a.out = d_out + (uint64_t) split * kRowOutputs;
+            a.n_rows = total_rows - split;
+            a.phase_rows = (uint32_t) (((offset + (uint64_t) split * kRowBytes) % B) / kRowBytes);
+            a.ragged_bytes = ragged;
+            a.halo = nullptr;
+            if (launch_rows(a, pl.in.taps, pl.out.taps, pl.conditioning, stream)) {
+                ctx->fail(DEMOD_E_HIP, "demod_rows (ragged) launch", hipGetLastError());
+                return DEMOD_E_HIP;
+            }
+        }
+        if (ctx->timing) {
+            HIP_TRY(ctx, hipEventRecord(ev.second, stream));
+            ctx->timed.push_back(ev);
+        }
+    }
+    if (forked) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->join_ev, 0));
+
+    if (tiny_tail) {
+        const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4, stream);
+        if (rc) return rc;
+    }
+    return DEMOD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-buffer path: pinned double buffering, hipMemcpyAsync on two streams
+// ---------------------------------------------------------------------------
+
+static int ensure_slots(demod_ctx *ctx) {
+    if (ctx->slots_ready) return DEMOD_OK;
+    for (auto &s : ctx->slot) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_in, kStageBytes, hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_out, kStageBytes, hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_halo, DEMOD_HALO_BYTES, hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc(&s.d_in, kStageBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_out, kStageBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_halo, DEMOD_HALO_BYTES));
+    }
+    ctx->slots_ready = true;
+    return DEMOD_OK;
+}
+
+static int drain_slot(demod_ctx *ctx, demod_ctx::Slot &s) {
+    if (!s.out_floats) return DEMOD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    memcpy(s.dst, s.h_out, s.out_floats * sizeof(float));
+    s.out_floats = 0;
+    return DEMOD_OK;
+}
+
+int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, float *h_out,
+                       const demod_span *span) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (n_bytes == 0) return DEMOD_OK;
+    if (!h_in_v || !h_out || (n_bytes & 3)) {
+        ctx->fail(DEMOD_E_INVAL, "null buffer or n_bytes not a multiple of 4");
+        return DEMOD_E_INVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_slots(ctx);
+    if (rc) return rc;
+
+    const uint8_t *h_in = static_cast<const uint8_t *>(h_in_v);
+    const uint64_t B = ctx->plan.chunk_bytes;
+    const uint64_t offset0 = span ? span->chunk_offset : 0;
+    const bool eos = span ? span->end_of_stream != 0 : true;
+    const uint8_t *tail_halo = span ? static_cast<const uint8_t *>(span->halo) : nullptr;
+
+    // pieces are whole chunks when a chunk fits the staging buffer, otherwise
+    // row-aligned cuts inside a chunk with the look-ahead taken from the host buffer
+    uint64_t piece = kStageBytes;
+    if (B <= kStageBytes) piece = kStageBytes / B * B;
+
+    uint64_t done = 0;
+    int which = 0;
+    while (done < n_bytes) {
+        uint64_t len = std::min(piece, n_bytes - done);
+        if (B <= kStageBytes && done == 0 && offset0) len = std::min(len, B - offset0);  // realign to chunks
+        demod_ctx::Slot &s = ctx->slot[which];
+        if ((rc = drain_slot(ctx, s))) return rc;
+
+        demod_span sp{};
+        sp.chunk_offset = B < kRowBytes ? 0 : (offset0 + done) % B;
+        const bool last = done + len == n_bytes;
+        sp.end_of_stream = last ? (eos ? 1u : 0u) : 0u;
+        const uint8_t *next = last ? tail_halo : h_in + done + len;
+        const bool ends_inside = B >= kRowBytes && ((offset0 + done + len) % B) != 0;
+        if (ends_inside && !sp.end_of_stream) {
+            if (last && !tail_halo) {
+                ctx->fail(DEMOD_E_INVAL, "buffer ends inside a chunk of a continuing stream: span.halo is required");
+                return DEMOD_E_INVAL;
+            }
+            // look-ahead bytes: what follows this piece in the host buffer, topped
+            // up from the caller's halo when the buffer itself runs out
+            uint8_t *hh = static_cast<uint8_t *>(s.h_halo);
+            memset(hh, 0, DEMOD_HALO_BYTES);
+            uint64_t have = 0;
+            if (!last) {
+                have = std::min<uint64_t>(DEMOD_HALO_BYTES, n_bytes - done - len);
+                memcpy(hh, next, have);
+            }
+            if (have < DEMOD_HALO_BYTES && tail_halo) memcpy(hh + have, tail_halo, DEMOD_HALO_BYTES - have);
+            HIP_TRY(ctx, hipMemcpyAsync(s.d_halo, hh, DEMOD_HALO_BYTES, hipMemcpyHostToDevice, s.stream));
+            sp.halo = s.d_halo;
+        }
+        memcpy(s.h_in, h_in + done, len);
+        HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, len, hipMemcpyHostToDevice, s.stream));
+        rc = demod_process_device(ctx, s.d_in, len, s.d_out, &sp, s.stream);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, len, hipMemcpyDeviceToHost, s.stream));
+        s.out_floats = len / 4;
+        s.dst = h_out + done / 4;
+        done += len;
+        which ^= 1;
+    }
+    for (auto &s : ctx->slot)
+        if ((rc = drain_slot(ctx, s))) return rc;
+    return DEMOD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// memory helpers, introspection, synthetic input
+// ---------------------------------------------------------------------------
+
+int demod_alloc_pinned(void **p, size_t len) {
+    if (!p) return DEMOD_E_INVAL;
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, len ? len : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return create_fail(DEMOD_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    memset(*p, 0, len);  // the reference's allocateBuffer callocs (src/matrix.c:282-285)
+    return DEMOD_OK;
+}
+
+void demod_free_pinned(void *p) {
+    if (p) (void) hipHostFree(p);
+}
+
+int demod_alloc_device(demod_ctx *ctx, void **p, size_t len) {
+    if (!ctx || !p) return DEMOD_E_INVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(p, len ? len : 1));
+    return DEMOD_OK;
+}
+
+void demod_free_device(demod_ctx *ctx, void *p) {
+    if (ctx && p) {
+        (void) hipSetDevice(ctx->device);
+        (void) hipFree(p);
+    }
+}
+
+int demod_copy_to_device(demod_ctx *ctx, void *d_dst, const void *h_src, size_t len) {
+    if (!ctx) return DEMOD_E_INVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(d_dst, h_src, len, hipMemcpyHostToDevice));
+    return DEMOD_OK;
+}
+
+int demod_copy_to_host(demod_ctx *ctx, void *h_dst, const void *d_src, size_t len) {
+    if (!ctx) return DEMOD_E_INVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(h_dst, d_src, len, hipMemcpyDeviceToHost));
+    return DEMOD_OK;
+}
+
+int demod_synchronize(demod_ctx *ctx) {
+    if (!ctx) return DEMOD_E_INVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return DEMOD_OK;
+}
+
+int demod_get_sos(const demod_ctx *ctx, int which, float *rows6, int max_rows) {
+    if (!ctx) return DEMOD_E_INVAL;
+    const Stage &st = which ? ctx->plan.in : ctx->plan.out;
+    const int n = std::min(st.sections, max_rows);
+    if (rows6)
+        for (int r = 0; r < n; ++r) memcpy(rows6 + 6 * r, st.sos[r], 6 * sizeof(float));
+    return st.sections;
+}
+
+int demod_get_taps(const demod_ctx *ctx, int which, float *taps, int max_taps, float *bias_im) {
+    if (!ctx) return DEMOD_E_INVAL;
+    const Stage &st = which ? ctx->plan.in : ctx->plan.out;
+    if (taps)
+        for (int j = 0; j < std::min(st.taps, max_taps); ++j) taps[j] = st.h[j];
+    if (bias_im) *bias_im = st.bias_im;
+    return st.taps;
+}
+
+int demod_get_head_outputs(const demod_ctx *ctx) { return ctx ? ctx->plan.head_outputs : DEMOD_E_INVAL; }
+
+int demod_design_query(const demod_params *p, int which, float *rows6, int max_rows, float *taps,
+                       int max_taps, float *bias_im, int *n_taps, int *head_outputs) {
+    if (!p) return create_fail(DEMOD_E_INVAL, "null argument");
+    Plan plan;
+    std::string err;
+    if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
+    const Stage &st = which ? plan.in : plan.out;
+    if (rows6)
+        for (int r = 0; r < std::min(st.sections, max_rows); ++r) memcpy(rows6 + 6 * r, st.sos[r], 6 * sizeof(float));
+    if (taps)
+        for (int j = 0; j < std::min(st.taps, max_taps); ++j) taps[j] = st.h[j];
+    if (bias_im) *bias_im = st.bias_im;
+    if (n_taps) *n_taps = st.taps;
+    if (head_outputs) *head_outputs = plan.head_outputs;
+    return st.sections;
+}
+
+int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed,
+                     void *stream) {
+    if (!ctx || !d_dst || (first_byte & 15) || (n_bytes & 15) || ((uintptr_t) d_dst & 15)) {
+        if (ctx) ctx->fail(DEMOD_E_INVAL, "synth_fill: 16-byte alignment required");
+        return DEMOD_E_INVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (launch_synth_fill(d_dst, first_byte, n_bytes, seed, stream)) {
+        ctx->fail(DEMOD_E_HIP, "synth_fill launch", hipGetLastError());
+        return DEMOD_E_HIP;
+    }
+    return DEMOD_OK;
+}
+
+// Device self-tests used by the GPU test-suite (not part of the data path).
+int demod_selftest_atan2(demod_ctx *ctx, const float *h_y, const float *h_x, float *h_out, uint32_t n) {
+    if (!ctx || !n) return DEMOD_E_INVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **) &d, 3ull * n * sizeof(float)));
+    int rc = DEMOD_OK;
+    if (hipMemcpy(d, h_y, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, h_x, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        launch_atan2_probe(d, d + n, d + 2ull * n, n, nullptr) != 0 ||
+        hipMemcpy(h_out, d + 2ull * n, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        ctx->fail(DEMOD_E_HIP, "atan2 self-test", hipGetLastError());
+        rc = DEMOD_E_HIP;
+    }
+    (void) hipFree(d);
+    return rc;
+}
+
+int demod_selftest_lane_shift(demod_ctx *ctx, const float *h_in64, float halo, float *h_out64) {
+    if (!ctx) return DEMOD_E_INVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **) &d, 128 * sizeof(float)));
+    int rc = DEMOD_OK;
+    if (hipMemcpy(d, h_in64, 64 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        launch_lane_probe(d, d + 64, halo, nullptr) != 0 ||
+        hipMemcpy(h_out64, d + 64, 64 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        ctx->fail(DEMOD_E_HIP, "lane-shift self-test", hipGetLastError());
+        rc = DEMOD_E_HIP;
+    }
+    (void) hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// kernels.h -- launch descriptors shared by the C-ABI layer (api.cpp) and the
+// HIP kernels (kernels.hip).  Plain structs passed to kernels by value.
+#pragma once
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace demod {
+
+constexpr uint32_t kRowBytes = 1024;   // one wavefront row: 64 lanes x 16 B of IQ
+constexpr uint32_t kRowOutputs = 256;  // float32 results per row: 64 lanes x 4
+
+// Main streaming kernel: rows [0, n_rows) of a device buffer.
+struct RowLaunch {
+    const uint8_t *in;
+    float *out;
+    const uint8_t *halo;   // DEMOD_HALO_BYTES that follow the buffer in the stream (device), or null
+    uint32_t n_rows;       // rows in the buffer; the last one may be ragged
+    uint32_t phase_rows;   // chunk-local row index of buffer row 0
+    uint32_t rpc_log2;     // log2(rows per chunk)
+    uint32_t seg_log2;     // log2(rows per wavefront segment), <= rpc_log2
+    uint32_t head_quads;   // lanes of a chunk's row 0 whose outputs belong to the head kernel
+    uint32_t ragged_bytes; // valid bytes of the last row (multiple of 4, < 1024), 0 = full
+    float hin[kMaxTaps];
+    float bias_im;
+    float hout[kMaxTaps];
+    float scale;           // normalizeInput: (float)(2./255.)
+};
+
+// Chunk-head kernel: literal replay of the sectioned recurrences over the first
+// few samples of every chunk that starts inside the buffer.
+struct HeadLaunch {
+    const uint8_t *in;         // first byte of the first chunk head
+    float *out;                // its first output
+    uint64_t chunk_bytes;      // distance between heads
+    uint32_t n_heads;
+    uint32_t head_outputs;     // outputs to produce per head (multiple of 4)
+    uint32_t last_chunk_bytes; // bytes of the last head's chunk (== chunk_bytes unless ragged tail)
+    int sec_in, sec_out;
+    float sos_in[kMaxSections][6];
+    float sos_out[kMaxSections][6];
+    float scale;
+};
+
+// Whole-chunk literal kernel for chunks smaller than one row (B < 1024).
+struct TinyLaunch {
+    const uint8_t *in;
+    float *out;
+    float *work;               // per-thread scratch, work_stride floats each
+    uint64_t work_stride;
+    uint64_t chunk_bytes;
+    uint64_t n_chunks;         // full chunks
+    uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
+    int sec_in, sec_out;
+    float sos_in[kMaxSections][6];
+    float sos_out[kMaxSections][6];
+    float scale;
+};
+
+// Host-callable launchers (defined in kernels.hip).  `stream` is a hipStream_t.
+int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream);
+int launch_heads(const HeadLaunch &a, int conditioning, void *stream);
+int launch_tiny(const TinyLaunch &a, int conditioning, uint32_t threads, void *stream);
+int launch_synth_fill(void *dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed, void *stream);
+// Device self-test helper: atan2 of n (y, x) pairs with the kernel's approximation.
+int launch_atan2_probe(const float *y, const float *x, float *out, uint32_t n, void *stream);
+// Device self-test helper: out[i] = value of lane i+1 (lane 63: halo) -- checks the DPP shift direction.
+int launch_lane_probe(const float *in, float *out, float halo, void *stream);
+
+}  // namespace demod

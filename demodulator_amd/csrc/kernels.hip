@@ -1,0 +1,587 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the FM-demodulation hot
+// path.  Compiled with -ffp-contract=off: every fused multiply-add below is an
+// explicit fmaf(), everything else rounds once per operation.
+//
+// demod_rows   the fused streaming kernel: uint8 IQ -> unpack -> [complex
+//              look-ahead stencil] -> conjugate-multiply discriminator + atan2
+//              -> real look-ahead stencil -> float32.  One wavefront streams a
+//              segment of 1 KiB rows from its end to its start, so the
+//              look-ahead values a row needs from the row after it are already
+//              in scalar registers; inside a row they come from the next lane
+//              by a DPP wave shift.  No LDS, no barriers, 16-byte loads and
+//              stores, 4 B of HBM traffic per IQ sample.
+// demod_heads  literal replay of the reference's sectioned recurrences for the
+//              first few outputs of every chunk (partial sections, overflow
+//              pollution).
+// demod_tiny   literal whole-chunk path for chunks shorter than one row.
+//
+// Reference semantics restated here (never copied):
+//   unpack         /root/reference/src/matrix.c:82-98, :100-118
+//   discriminator  src/matrix.c:159-176
+//   filters        src/filter.c:212-231 (real), :233-259 (complex)
+//   chunk loop     src/matrix.c:236-273
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace demod {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kPi = 3.14159274101257324f;      // (float) pi, what atan2f returns on the negative real axis
+constexpr float kHalfPi = 1.57079637050628662f;  // (float) (pi / 2)
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+
+// Lane i receives the value lane i + 1 holds; lane 63 receives `halo`.
+// One v_mov_b32 with DPP wave_shl:1 (gfx9 family); `halo` is the DPP "old"
+// operand, kept by the lane that has no source.
+__device__ __forceinline__ float from_next_lane(float v, float halo) {
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(halo), __float_as_int(v), 0x130, 0xF,
+                                              0xF, false);
+    return __int_as_float(r);
+}
+
+__device__ __forceinline__ float wave_first(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// atan2(y, x) for finite arguments with IEEE signed-zero behaviour:
+//   atan2(+-0, x >= +0) = +-0, atan2(+-0, x <= -0) = +-pi  (SURVEY.md Appendix A.2).
+// Octant reduction to q = min/max in [0, 1], odd minimax polynomial q*P(q^2)
+// (8 coefficients, |error| < 7e-8 before rounding), one v_rcp_f32.
+__device__ __forceinline__ float fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float hi = fmaxf(fmaxf(ax, ay), FLT_MIN);  // never 0: atan2(0, 0) must come out as 0 or pi
+    const float lo = fminf(ax, ay);
+    const float q = lo * __builtin_amdgcn_rcpf(hi);
+    const float s = q * q;
+    float p = -4.054567311e-03f;
+    p = fmaf(p, s, 2.186295763e-02f);
+    p = fmaf(p, s, -5.591232702e-02f);
+    p = fmaf(p, s, 9.642197192e-02f);
+    p = fmaf(p, s, -1.390862912e-01f);
+    p = fmaf(p, s, 1.994656622e-01f);
+    p = fmaf(p, s, -3.332985938e-01f);
+    p = fmaf(p, s, 9.999993443e-01f);
+    float r = p * q;
+    r = ay > ax ? kHalfPi - r : r;
+    r = __float_as_int(x) < 0 ? kPi - r : r;  // sign bit, so -0 counts as negative
+    return copysignf(r, y);
+}
+
+// Quadrature discriminator of one pair of complex samples z0 = a + ib,
+// z1 = c + id: arg(z0 * conj(z1)), src/matrix.c:170-173.
+__device__ __forceinline__ float discriminate(float a, float b, float c, float d) {
+    const float zr = fmaf(b, d, a * c);
+    const float zj = fmaf(b, c, (-a) * d);
+    return fast_atan2(zj, zr);
+}
+
+// Four bytes -> (byte - 127) wrapped to int8, all four at once (SWAR):
+// per byte, ((b | 0x80) - 0x7f) is (b & 0x7f) + 1 with no borrow between bytes;
+// xor with the inverted top bit adds the +128 for b < 128.
+__device__ __forceinline__ uint32_t rebias4(uint32_t w) {
+    const uint32_t q = (w | 0x80808080u) - 0x7F7F7F7Fu;
+    return q ^ (~w & 0x80808080u);
+}
+
+template <int COND>
+__device__ __forceinline__ void unpack_dword(uint32_t w, float scale, float &i0, float &q0, float &i1,
+                                             float &q1) {
+    if constexpr (COND == kNormalize) {
+        // byte * (2/255) - 1, product and difference rounded separately (src/matrix.c:106,112)
+        i0 = (float) (w & 0xFFu) * scale - 1.0f;
+        q0 = (float) ((w >> 8) & 0xFFu) * scale - 1.0f;
+        i1 = (float) ((w >> 16) & 0xFFu) * scale - 1.0f;
+        q1 = (float) (w >> 24) * scale - 1.0f;
+    } else {
+        // (int8_t)(byte - 127): 255 -> -128, 127 -> +0 (src/matrix.c:92-96)
+        const uint32_t u = rebias4(w);
+        i0 = (float) (int8_t) (u & 0xFFu);
+        q0 = (float) (int8_t) ((u >> 8) & 0xFFu);
+        i1 = (float) (int8_t) ((u >> 16) & 0xFFu);
+        q1 = (float) (int8_t) (u >> 24);
+    }
+}
+
+template <int COND>
+__device__ __forceinline__ float unpack_byte(uint8_t b, float scale) {
+    if constexpr (COND == kNormalize) return (float) b * scale - 1.0f;
+    return (float) (int8_t) (uint8_t) (b - 127);
+}
+
+// Look-ahead values a row needs from the row after it (lane 0 of that row).
+struct Halo {
+    float xr[kMaxTaps - 1];  // re of its first complex samples
+    float xi[kMaxTaps - 1];
+    float d[kMaxTaps - 1];   // its first discriminator outputs
+};
+
+// T-tap forward stencil  sum_j h[j] * v[j]  (+ c0 folded into the first product)
+template <int T>
+__device__ __forceinline__ float stencil(const float *h, const float *v, float c0) {
+    float acc = fmaf(h[0], v[0], c0);
+#pragma unroll
+    for (int j = 1; j < T; ++j) acc = fmaf(h[j], v[j], acc);
+    return acc;
+}
+template <int T>
+__device__ __forceinline__ float stencil0(const float *h, const float *v) {
+    float acc = h[0] * v[0];
+#pragma unroll
+    for (int j = 1; j < T; ++j) acc = fmaf(h[j], v[j], acc);
+    return acc;
+}
+
+// One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
+// `valid` = usable bytes of this lane's 16 (16 unless RAGGED).
+// halo: in  = look-ahead from the following row (lane 0 of it),
+//       out = this row's lane-0 values for the row before it.
+template <int TIN, int TOUT, int COND, bool RAGGED>
+__device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, Halo &halo, int valid,
+                                            float (&y)[4]) {
+    constexpr int NX = 8 + (TIN > 0 ? TIN - 1 : 0);
+    constexpr int ND = 4 + TOUT - 1;
+    float xr[NX], xi[NX];
+    unpack_dword<COND>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+    unpack_dword<COND>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+    unpack_dword<COND>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+    unpack_dword<COND>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+    if constexpr (RAGGED) {
+        // past the end of a short final chunk the reference's buffers hold 0.0f
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool ok = 2 * k < valid;
+            xr[k] = ok ? xr[k] : 0.f;
+            xi[k] = ok ? xi[k] : 0.f;
+        }
+    }
+
+    float d[ND];
+    if constexpr (TIN > 0) {
+        // complex samples 8.. come from the next lane
+#pragma unroll
+        for (int j = 0; j < TIN - 1; ++j) {
+            xr[8 + j] = from_next_lane(xr[j], halo.xr[j]);
+            xi[8 + j] = from_next_lane(xi[j], halo.xi[j]);
+        }
+        float zr[8], zi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            zr[k] = stencil0<TIN>(a.hin, &xr[k]);
+            zi[k] = stencil<TIN>(a.hin, &xi[k], a.bias_im);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = discriminate(zr[2 * j], zi[2 * j], zr[2 * j + 1], zi[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = discriminate(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1]);
+    }
+    if constexpr (RAGGED) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = 4 * j < valid ? d[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TOUT - 1; ++j) d[4 + j] = from_next_lane(d[j], halo.d[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = stencil0<TOUT>(a.hout, &d[j]);
+
+    // hand this row's lane-0 values to the row before it
+    if constexpr (TIN > 1) {
+#pragma unroll
+        for (int j = 0; j < TIN - 1; ++j) {
+            halo.xr[j] = wave_first(xr[j]);
+            halo.xi[j] = wave_first(xi[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TOUT - 1; ++j) halo.d[j] = wave_first(d[j]);
+}
+
+__device__ __forceinline__ uint4 load_row16(const uint8_t *row_base, uint32_t lane) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row_base) + lane);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ void store_out16(float *dst, const float (&y)[4]) {
+    f32x4 v;
+    v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+}
+
+// 16 bytes of a ragged row: only `valid` (multiple of 4) bytes exist.
+__device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint32_t lane, int valid) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(row_base) + 4 * lane;
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (valid >= 4) w.x = p[0];
+    if (valid >= 8) w.y = p[1];
+    if (valid >= 12) w.z = p[2];
+    if (valid >= 16) w.w = p[3];
+    return w;
+}
+
+// ---------------------------------------------------------------------------
+// the fused streaming kernel
+// ---------------------------------------------------------------------------
+template <int TIN, int TOUT, int COND, bool RAGGED>
+__global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t seg = blockIdx.x * 4u + wave;
+
+    // rows are numbered from the start of the chunk that encloses buffer row 0
+    const uint32_t g0 = a.phase_rows;
+    const uint32_t g1 = g0 + a.n_rows;
+    uint32_t gb = ((g0 >> a.seg_log2) + seg) << a.seg_log2;
+    uint32_t ge = gb + (1u << a.seg_log2);
+    gb = gb < g0 ? g0 : gb;
+    ge = ge > g1 ? g1 : ge;
+    if (gb >= ge) return;
+    const uint32_t rb = gb - g0, re = ge - g0;  // buffer rows [rb, re), processed from re-1 down to rb
+    const uint32_t rpc_mask = (1u << a.rpc_log2) - 1u;
+    const uint32_t last_row = a.n_rows - 1u;
+
+    auto lane_valid = [&](uint32_t r) -> int {
+        if constexpr (!RAGGED) return 16;
+        if (r != last_row || a.ragged_bytes == 0) return 16;
+        const int v = (int) a.ragged_bytes - (int) (lane * 16u);
+        return v < 0 ? 0 : (v > 16 ? 16 : v);
+    };
+    auto load = [&](uint32_t r) -> uint4 {
+        const uint8_t *base = a.in + (uint64_t) r * kRowBytes;
+        if constexpr (RAGGED) {
+            if (r == last_row && a.ragged_bytes != 0) return load_row16_ragged(base, lane, lane_valid(r));
+        }
+        return load_row16(base, lane);
+    };
+
+    // look-ahead for the last row of the segment
+    Halo halo;
+#pragma unroll
+    for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = halo.d[j] = 0.f;
+    if ((ge & rpc_mask) != 0) {
+        // The segment ends inside a chunk: run the row that follows once, only
+        // for the lane-0 values it hands back (they depend on its first lanes
+        // alone, so the unknown look-ahead of that row itself does not matter).
+        float unused[4];
+        if (re < a.n_rows) {
+            process_row<TIN, TOUT, COND, RAGGED>(load(re), a, halo, lane_valid(re), unused);
+        } else if (a.halo != nullptr) {
+            // the stream continues on another shard: its first DEMOD_HALO_BYTES bytes
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (lane < DEMOD_HALO_BYTES / 16u) w = reinterpret_cast<const uint4 *>(a.halo)[lane];
+            process_row<TIN, TOUT, COND, false>(w, a, halo, 16, unused);
+        }
+        // else: the stream ends here (short final chunk): zeros, as the reference's buffers hold
+    }
+
+    uint4 cur = load(re - 1u);
+    for (uint32_t r = re; r-- > rb;) {
+        uint4 nxt = cur;
+        if (r > rb) nxt = load(r - 1u);
+
+        float y[4];
+        const int valid = lane_valid(r);
+        process_row<TIN, TOUT, COND, RAGGED>(cur, a, halo, valid, y);
+
+        const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
+        float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
+        if constexpr (RAGGED) {
+            if (!head) {
+                if (valid >= 16) {
+                    store_out16(dst, y);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * j < valid) dst[j] = y[j];
+                }
+            }
+        } else {
+            if (!head) store_out16(dst, y);
+        }
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// chunk heads: literal replay over a short window (one thread per chunk)
+// ---------------------------------------------------------------------------
+constexpr int kHeadMaxOut = 32;                                  // ceil4(max(2*8-1, 4*8-2))
+constexpr int kHeadMaxD = kHeadMaxOut + kMaxSections + 2;        // discriminator values needed
+constexpr int kHeadMaxZ = 2 * kHeadMaxD + 2 * kMaxSections + 2;  // complex cells simulated
+
+template <int COND>
+__global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_heads) return;
+    const uint8_t *bytes = a.in + (uint64_t) c * a.chunk_bytes;
+    float *out = a.out + (uint64_t) c * (a.chunk_bytes >> 2);
+    const uint32_t chunk = (c == a.n_heads - 1) ? a.last_chunk_bytes : (uint32_t) a.chunk_bytes;
+    const int K = (int) (chunk >> 1);   // complex samples in this chunk
+    const int Ld = (int) (chunk >> 2);  // outputs of this chunk
+    const int Si = a.sec_in, So = a.sec_out;
+    const int H = (int) a.head_outputs;
+    const int W = H + So + 1;           // discriminator values d[0..W) feed outputs [0, H)
+
+    float d[kHeadMaxD];
+    float yc[kHeadMaxD + 1];
+    for (int n = 0; n <= W; ++n) yc[n] = 0.f;
+
+    auto sample = [&](int k, int lane01) -> float {  // unpacked input, 0.0f past the chunk
+        return k < K ? unpack_byte<COND>(bytes[2 * k + lane01], a.scale) : 0.f;
+    };
+
+    if (Si > 0) {
+        // complex stage, src/filter.c:242-258, cells [0, NZ) brought to their final value
+        float zr[kHeadMaxZ], zi[kHeadMaxZ];
+        const int NZ = 2 * W;
+        for (int k = 0; k < NZ + 2 * Si + 2; ++k) zr[k] = zi[k] = 0.f;
+        for (int i = 0; i + Si < NZ; ++i) {  // iteration i finalises cell i + Si
+            for (int m = 0; m < Si; ++m) {
+                const int n = i + Si + m;
+                const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
+                const float a0 = a.sos_in[m][3], a1 = a.sos_in[m][4], a2 = a.sos_in[m][5];
+                float t = b0 * zr[n] + b1 * zr[n + 1] + 1.0f;
+                zr[n] = t - (a0 + a1 * sample(n, 0) + a2 * sample(n + 1, 0));
+                t = b0 * zi[n] + b1 * zi[n + 1];
+                zi[n] = t - (a0 + a1 * sample(n, 1) + a2 * sample(n + 1, 1));
+            }
+        }
+        // cells K .. K+2Si-2 overflow into the output stage's buffer.  Their
+        // "input" is the aliased head of the complex stage's own output
+        // (x[K + t] == z[t]); the last 2Si-1 iterations write them.
+        float ovr[2 * kMaxSections + 1], ovi[2 * kMaxSections + 1];
+        for (int t = 0; t <= 2 * Si; ++t) ovr[t] = ovi[t] = 0.f;
+        for (int i = K - 2 * Si + 1; i < K; ++i) {
+            for (int m = 0; m < Si; ++m) {
+                const int t = i + Si + m - K;
+                if (t < 0) continue;
+                const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
+                const float a0 = a.sos_in[m][3], a1 = a.sos_in[m][4], a2 = a.sos_in[m][5];
+                float u = b0 * ovr[t] + b1 * ovr[t + 1] + 1.0f;
+                ovr[t] = u - (a0 + a1 * zr[t] + a2 * zr[t + 1]);
+                u = b0 * ovi[t] + b1 * ovi[t + 1];
+                ovi[t] = u - (a0 + a1 * zi[t] + a2 * zi[t + 1]);
+            }
+        }
+        for (int t = 0; t < 2 * Si - 1; ++t) {
+            if (2 * t <= W) yc[2 * t] = ovr[t];
+            if (2 * t + 1 <= W) yc[2 * t + 1] = ovi[t];
+        }
+        for (int n = 0; n < W; ++n)
+            d[n] = n < Ld ? discriminate(zr[2 * n], zi[2 * n], zr[2 * n + 1], zi[2 * n + 1]) : 0.f;
+    } else {
+        for (int n = 0; n < W; ++n)
+            d[n] = n < Ld ? discriminate(sample(2 * n, 0), sample(2 * n, 1), sample(2 * n + 1, 0),
+                                         sample(2 * n + 1, 1))
+                          : 0.f;
+    }
+    d[W] = 0.f;  // never reaches an output below H; keeps the window reads defined
+
+    // real stage, src/filter.c:221-230: iteration i finalises cell i + So
+    for (int i = 0; i + So < H && i < Ld; ++i) {
+        for (int m = 0; m < So; ++m) {
+            const int n = i + So + m;
+            const float b0 = a.sos_out[m][0], b1 = a.sos_out[m][1];
+            const float a0 = a.sos_out[m][3], a1 = a.sos_out[m][4], a2 = a.sos_out[m][5];
+            const float t = b0 * yc[n] + b1 * yc[n + 1] + 1.0f;
+            yc[n] = t - (a0 + a1 * d[n] + a2 * d[n + 1]);
+        }
+    }
+    for (int n = 0; n < H; n += 4)
+        *reinterpret_cast<float4 *>(out + n) = make_float4(yc[n], yc[n + 1], yc[n + 2], yc[n + 3]);
+}
+
+// ---------------------------------------------------------------------------
+// chunks shorter than one row: literal whole-chunk replay (one thread per chunk)
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTinyPad = 4 * kMaxSections + 8;
+
+template <int COND>
+__global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
+    const uint64_t tid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t) gridDim.x * blockDim.x;
+    const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
+    float *F = a.work + tid * a.work_stride;
+    const int Si = a.sec_in, So = a.sec_out;
+
+    for (uint64_t c = tid; c < total; c += nthreads) {
+        const uint32_t B = c < a.n_chunks ? (uint32_t) a.chunk_bytes : a.tail_bytes;
+        const uint8_t *bytes = a.in + c * a.chunk_bytes;
+        float *out = a.out + c * (a.chunk_bytes >> 2);
+        const uint32_t Ld = B >> 2;
+        // same buffer layout as the reference (src/matrix.c:184-187,228,234):
+        // work = 2B floats (4B with the input filter) and a separate B-float
+        // demod buffer; both padded so that the recurrences' reach past the
+        // end (which the reference leaves to the heap) stays in zeroed scratch.
+        float *dem = F + 4 * a.chunk_bytes + kTinyPad;
+        for (uint64_t i = 0; i < a.work_stride; ++i) F[i] = 0.f;
+
+        for (uint32_t i = 0; i < B; ++i) F[i] = unpack_byte<COND>(bytes[i], a.scale);
+        float *src = F;
+        float *y2 = F + B;
+        if (Si > 0) {
+            float *x = F, *y = F + B;  // x[B + t] aliases y[t], exactly as in the reference
+            for (uint32_t i = 0; i < B; i += 2) {
+                for (int m = 0; m < Si; ++m) {
+                    const uint32_t n = i + 2 * Si + 2 * m;
+                    const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
+                    const float a0 = a.sos_in[m][3], a1 = a.sos_in[m][4], a2 = a.sos_in[m][5];
+                    float t = b0 * y[n] + b1 * y[n + 2] + 1.0f;
+                    y[n] = t - (a0 + a1 * x[n] + a2 * x[n + 2]);
+                    t = b0 * y[n + 1] + b1 * y[n + 3];
+                    y[n + 1] = t - (a0 + a1 * x[n + 1] + a2 * x[n + 3]);
+                }
+            }
+            src = F + B;
+            y2 = F + 2 * B;
+        }
+        for (uint32_t n = 0; n < Ld; ++n)
+            dem[n] = discriminate(src[4 * n], src[4 * n + 1], src[4 * n + 2], src[4 * n + 3]);
+        for (uint32_t i = 0; i < Ld; ++i) {
+            for (int m = 0; m < So; ++m) {
+                const uint32_t n = i + So + m;
+                const float b0 = a.sos_out[m][0], b1 = a.sos_out[m][1];
+                const float a0 = a.sos_out[m][3], a1 = a.sos_out[m][4], a2 = a.sos_out[m][5];
+                const float t = b0 * y2[n] + b1 * y2[n + 1] + 1.0f;
+                y2[n] = t - (a0 + a1 * dem[n] + a2 * dem[n + 1]);
+            }
+        }
+        for (uint32_t n = 0; n < Ld; ++n) out[n] = y2[n];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// synthetic input and self-test probes
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64_word(uint64_t seed, uint64_t j) {
+    uint64_t z = seed + (j + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_fill(uint64_t *dst, uint64_t first_word, uint64_t n_pairs,
+                                                  uint64_t seed) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += stride) {
+        const uint64_t j = first_word + 2 * p;
+        ulonglong2 v;
+        v.x = splitmix64_word(seed, j);
+        v.y = splitmix64_word(seed, j + 1);
+        reinterpret_cast<ulonglong2 *>(dst)[p] = v;
+    }
+}
+
+__global__ void atan2_probe(const float *y, const float *x, float *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fast_atan2(y[i], x[i]);
+}
+
+__global__ void lane_probe(const float *in, float *out, float halo) {
+    out[threadIdx.x] = from_next_lane(in[threadIdx.x], halo);
+}
+
+inline int hip_ok(hipError_t e) { return e == hipSuccess ? 0 : -(int) e - 1000; }
+
+template <int TIN, int TOUT, int COND>
+int launch_rows_t(const RowLaunch &a, hipStream_t s) {
+    const uint32_t g0 = a.phase_rows, g1 = a.phase_rows + a.n_rows;
+    const uint32_t segs = ((g1 + (1u << a.seg_log2) - 1u) >> a.seg_log2) - (g0 >> a.seg_log2);
+    const uint32_t blocks = (segs + 3u) / 4u;
+    if (a.ragged_bytes)
+        hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, true>), dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false>), dim3(blocks), dim3(256), 0, s, a);
+    return hip_ok(hipGetLastError());
+}
+
+template <int COND>
+int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
+    // specialised stencil lengths for the common designs, a 5-tap build for the rest
+    if (tin <= 3 && tout <= 3) {
+        switch (tin * 4 + tout) {
+        case 0 * 4 + 1: return launch_rows_t<0, 1, COND>(a, s);
+        case 0 * 4 + 2: return launch_rows_t<0, 2, COND>(a, s);
+        case 0 * 4 + 3: return launch_rows_t<0, 3, COND>(a, s);
+        case 1 * 4 + 1: return launch_rows_t<1, 1, COND>(a, s);
+        case 1 * 4 + 2: return launch_rows_t<1, 2, COND>(a, s);
+        case 1 * 4 + 3: return launch_rows_t<1, 3, COND>(a, s);
+        case 2 * 4 + 1: return launch_rows_t<2, 1, COND>(a, s);
+        case 2 * 4 + 2: return launch_rows_t<2, 2, COND>(a, s);
+        case 2 * 4 + 3: return launch_rows_t<2, 3, COND>(a, s);
+        case 3 * 4 + 1: return launch_rows_t<3, 1, COND>(a, s);
+        case 3 * 4 + 2: return launch_rows_t<3, 2, COND>(a, s);
+        case 3 * 4 + 3: return launch_rows_t<3, 3, COND>(a, s);
+        default: break;
+        }
+    }
+    // zero-padded taps make the long stencils exact for any shorter design
+    if (tin == 0) return launch_rows_t<0, kMaxTaps, COND>(a, s);
+    return launch_rows_t<kMaxTaps, kMaxTaps, COND>(a, s);
+}
+
+}  // namespace
+
+int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.n_rows == 0) return 0;
+    if (conditioning == kNormalize) return launch_rows_c<kNormalize>(a, taps_in, taps_out, s);
+    return launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s);
+}
+
+int launch_heads(const HeadLaunch &a, int conditioning, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.n_heads == 0 || a.head_outputs == 0) return 0;
+    const uint32_t blocks = (a.n_heads + 63u) / 64u;
+    if (conditioning == kNormalize)
+        hipLaunchKernelGGL(demod_heads<kNormalize>, dim3(blocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(demod_heads<kShiftOrigin>, dim3(blocks), dim3(64), 0, s, a);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_tiny(const TinyLaunch &a, int conditioning, uint32_t threads, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t blocks = (threads + 63u) / 64u;
+    if (blocks == 0) return 0;
+    if (conditioning == kNormalize)
+        hipLaunchKernelGGL(demod_tiny<kNormalize>, dim3(blocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(demod_tiny<kShiftOrigin>, dim3(blocks), dim3(64), 0, s, a);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_synth_fill(void *dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t pairs = n_bytes / 16;
+    if (pairs == 0) return 0;
+    uint64_t blocks = (pairs + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(synth_fill, dim3((uint32_t) blocks), dim3(256), 0, s, static_cast<uint64_t *>(dst),
+                       first_byte / 8, pairs, seed);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_atan2_probe(const float *y, const float *x, float *out, uint32_t n, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(atan2_probe, dim3((n + 255u) / 256u), dim3(256), 0, s, y, x, out, n);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_lane_probe(const float *in, float *out, float halo, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lane_probe, dim3(1), dim3(64), 0, s, in, out, halo);
+    return hip_ok(hipGetLastError());
+}
+
+}  // namespace demod

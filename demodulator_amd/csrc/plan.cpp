@@ -1,0 +1,229 @@
+// plan.cpp -- filter design and stencil derivation (host, once per context).
+#include "plan.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+namespace demod {
+
+Options options_from_params(const demod_params &p) {
+    Options o;
+    o.sample_rate = p.sample_rate;
+    o.lowpass_in = p.lowpass_in;
+    o.lowpass_out = p.lowpass_out;
+    o.epsilon = p.epsilon;
+    o.in_degree = p.in_degree;
+    o.out_degree = p.out_degree;
+    o.mode = p.mode;
+    o.buf_size = p.buf_size;
+    return o;
+}
+
+namespace {
+
+using ld = long double;
+
+// One z-plane pole (upper member of a conjugate pair, or a real pole) plus the
+// factor it contributes to the overall gain.
+struct Pole {
+    ld re, im;  // pole location
+    ld g;       // gain factor argument (the reference's "zr")
+};
+
+// The reference spells pi and pi/2 with the double-precision macros even in
+// long double arithmetic (src/matrix.c:34, src/filter.c:29,69); the design
+// must use the same constants to land on the same float coefficients.
+constexpr double kPi = M_PI;
+constexpr double kHalfPi = M_PI_2;
+
+// Butterworth pole k of n under the pre-warped bilinear map
+// (src/filter.c:28-39; highpass gain term src/filter.c:48).
+Pole butterworth_pole(ld inv_sin2w, ld tanw, size_t k, size_t n, bool highpass) {
+    const ld frac = 1. / (ld) n * (-1. + (ld) (2 * k));
+    const ld theta = kHalfPi * (frac + 1.);
+    const ld c = cosl(theta);
+    const ld inv = 1. / (c - inv_sin2w);
+    const ld zr = (-tanw + c) * inv;
+    const ld zj = sinl(theta) * inv;
+    return Pole{-zr + 1., zj, highpass ? 2. - zr : zr};
+}
+
+// Chebyshev type-I pole k of n (src/filter.c:66-82).
+Pole chebyshev1_pole(ld tng, ld ripple, size_t k, size_t n) {
+    const ld inv_n = 1. / (ld) n;
+    const ld v = logl((1. + powl(10., 0.5 * ripple)) / sqrtl(-1. + powl(10., ripple))) * inv_n;
+    const ld t = kHalfPi * (inv_n * (-1. + (ld) (2 * k)));
+    const ld a = cosl(t) * coshl(v) * tng;
+    const ld b = sinl(t) * sinhl(v) * tng;
+    const ld c = a * a + b * b;
+    const ld inv = 1. / (1. + c + 2. * b);
+    const ld zj = 2. * a * inv;
+    const ld zr = 2. * (b + c) * inv;
+    return Pole{-zr + 1., zj, zr};
+}
+
+}  // namespace
+
+void design_sections(unsigned kind, size_t degree, long double fc, long double fs,
+                     long double epsilon, float (*sos)[6]) {
+    const size_t n = degree;
+    if (n == 0) return;
+    const size_t pairs = n / 2;
+    const bool odd = (n % 2) != 0;
+    const size_t rows = pairs + (odd ? 1 : 0);
+    const bool highpass = kind == 2 || kind == 3;
+    const bool cheby = kind == 1 || kind == 3;
+
+    // src/matrix.c:34,37
+    const ld w = kPi * fc / fs;
+    const ld wh = coshl(1. / (ld) n * acoshl(1. / sqrtl(powl(10., epsilon) - 1.)));
+
+    std::vector<Pole> poles(rows);
+    for (size_t k = 1; k <= rows; ++k) {
+        if (cheby) {
+            const ld tng = tanl(w * wh);  // src/matrix.c:53,65
+            poles[k - 1] = chebyshev1_pole(kind == 3 ? 1. / tng : tng, epsilon, k, n);
+        } else {
+            poles[k - 1] = butterworth_pole(1. / sinl(2. * w), tanl(w), k, n, highpass);  // :59,71
+        }
+    }
+
+    // Gain: product over the poles, conjugate pairs as |.|^2, an unpaired pole
+    // as a complex factor; even-order Chebyshev lowpass starts at 1/sqrt(2);
+    // normalised by 2^n (src/filter.c:153,165-184).
+    ld gr = (!odd && kind == 1) ? (ld) M_SQRT1_2 : (ld) 1., gi = 0;
+    for (size_t k = 1; k <= rows; ++k) {
+        const Pole &p = poles[k - 1];
+        if (k <= pairs) {
+            const ld mag2 = p.g * p.g + p.im * p.im;
+            gr *= mag2;
+            gi *= mag2;
+        } else {
+            const ld t = p.g * gr - p.im * gi;
+            gi = p.g * gi + p.im * gr;
+            gr = t;
+        }
+    }
+    const ld gain = gr / (ld) (1 << n);
+
+    // Rows: zeros all at z = -1 (lowpass) or +1 (highpass); the gain scales the
+    // numerator of the last row (src/filter.c:104-140).
+    const ld z0 = highpass ? 1 : -1;
+    std::vector<std::array<ld, 6>> rows_ld(rows);
+    for (size_t j = 0; j < pairs; ++j) {
+        const Pole &p = poles[j];
+        rows_ld[j] = {(ld) 1., -2. * z0, z0 * z0 + (ld) 0. * (ld) 0., (ld) 1., -2. * p.re,
+                      p.re * p.re + p.im * p.im};
+    }
+    if (odd) rows_ld[pairs] = {(ld) 1., -z0, (ld) 0., (ld) 1., -poles[pairs].re, (ld) 0.};
+    auto &last = rows_ld[rows - 1];
+    last[0] *= gain;
+    last[1] *= gain;
+    last[2] *= gain;
+
+    for (size_t r = 0; r < rows; ++r)
+        for (int c = 0; c < 6; ++c) sos[r][c] = (float) rows_ld[r][c];  // src/matrix.c:75-79
+}
+
+void derive_taps(Stage &st) {
+    // Section m leaves in cell n:
+    //   P(n,m) = b0[m] P(n,m+1) + b1[m] P(n+1,m+2) - a1[m] x[n] - a2[m] x[n+1]  (+1 - a0[m] real lane,
+    //                                                                              - a0[m] imaginary lane)
+    // with P(.,S) = P(.,S+1) = 0.  P(n,0) as a linear
+    // form in x[n + j] gives the taps; the constant term gives the bias.
+    const int S = st.sections;
+    std::vector<std::vector<double>> coef(S + 2, std::vector<double>(S + 3, 0.0));
+    std::vector<double> bias(S + 2, 0.0);
+    for (int m = S - 1; m >= 0; --m) {
+        const double b0 = st.sos[m][0], b1 = st.sos[m][1];
+        for (int j = 0; j < S + 3; ++j) {
+            double c = b0 * coef[m + 1][j];
+            if (j > 0) c += b1 * coef[m + 2][j - 1];
+            coef[m][j] = c;
+        }
+        coef[m][0] -= (double) st.sos[m][4];
+        coef[m][1] -= (double) st.sos[m][5];
+        bias[m] = b0 * bias[m + 1] + b1 * bias[m + 2] - (double) st.sos[m][3];
+    }
+    int taps = 1;
+    for (int j = 0; j < S + 3; ++j)
+        if (coef[0][j] != 0.0) taps = j + 1;
+    st.taps = taps;
+    for (int j = 0; j < kMaxTaps; ++j) st.h[j] = j < taps ? (float) coef[0][j] : 0.f;
+    st.bias_im = (float) bias[0];
+}
+
+bool build_plan(const Options &o, Plan &plan, std::string &err) {
+    char msg[256];
+    const unsigned demod_mode = (o.mode >> 4) & 3;
+    const unsigned iq_mode = (o.mode >> 2) & 3;
+    size_t in_degree = o.in_degree;
+
+    if (demod_mode == 0) {
+        err = "demod mode 0 (raw filtered IQ output, src/matrix.c:244-251) is not part of this path";
+        return false;
+    }
+    if (iq_mode == 1 || iq_mode == 2) {
+        err = "-q1 (correctIq) and -q2 (highpassDc) IQ conditioning are not supported";
+        return false;
+    }
+    if (o.buf_size < 4 || (o.buf_size & (o.buf_size - 1))) {
+        err = "chunk size must be a power of two >= 4 bytes";
+        return false;
+    }
+    // src/matrix.c:190-192: -L without -D filters the input with the output degree
+    if (o.lowpass_in != 0 && in_degree == 0) in_degree = o.out_degree;
+    if (in_degree != 0 && o.lowpass_in == 0) {
+        err = "-D without -L is undefined in the reference (uninitialised input filter, "
+              "src/matrix.c:227-231,254) and is rejected";
+        return false;
+    }
+    if (o.out_degree < 1 || o.out_degree > DEMOD_MAX_DEGREE || in_degree > DEMOD_MAX_DEGREE) {
+        snprintf(msg, sizeof msg, "filter degree out of range (1..%u)", DEMOD_MAX_DEGREE);
+        err = msg;
+        return false;
+    }
+    if (!(o.sample_rate > 0) || !(o.lowpass_out > 0) || o.lowpass_in < 0) {
+        err = "sample rate and cutoff frequencies must be positive";
+        return false;
+    }
+
+    plan = Plan{};
+    plan.chunk_bytes = o.buf_size;
+    plan.conditioning = iq_mode == 3 ? kNormalize : kShiftOrigin;
+    plan.prefilter = in_degree != 0;
+
+    plan.out.sections = (int) ((o.out_degree + 1) / 2);
+    design_sections(o.mode & 1, o.out_degree, o.lowpass_out, o.sample_rate, o.epsilon,
+                    plan.out.sos);  // src/matrix.c:224-225
+    derive_taps(plan.out);
+    if (plan.prefilter) {
+        plan.in.sections = (int) ((in_degree + 1) / 2);
+        design_sections((o.mode >> 1) & 1, in_degree, o.lowpass_in, o.sample_rate, o.epsilon,
+                        plan.in.sos);  // src/matrix.c:229-230
+        derive_taps(plan.in);
+    }
+    for (const Stage *st : {&plan.in, &plan.out})
+        for (int r = 0; r < st->sections; ++r)
+            for (int c = 0; c < 6; ++c)
+                if (!std::isfinite(st->sos[r][c])) {
+                    err = "filter design produced non-finite coefficients for these options";
+                    return false;
+                }
+    if (plan.in.taps > kMaxTaps || plan.out.taps > kMaxTaps) {
+        err = "stencil longer than supported";
+        return false;
+    }
+
+    // Outputs at the head of every chunk that are not interior (partial
+    // sections, cells polluted by the complex stage's overflow; SURVEY.md
+    // Appendix A.4): n < max(2*S_out - 1, 4*S_in - 2).
+    plan.head_outputs = std::max(2 * plan.out.sections - 1, 4 * plan.in.sections - 2);
+    plan.head_quads = (plan.head_outputs + 3) / 4;
+    return true;
+}
+
+}  // namespace demod

@@ -1,0 +1,67 @@
+// plan.h -- host-side setup of the demodulation path: filter design, stencil
+// taps, chunk-head extent.  Runs once per context; nothing here is on the
+// per-sample path.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "demod_hip.h"
+
+namespace demod {
+
+constexpr int kMaxSections = (DEMOD_MAX_DEGREE + 1) / 2;  // 8
+constexpr int kMaxTaps = 5;                               // look-ahead stencil length for degree <= 16
+
+// Options with the reference's own precision (consumerArgs holds long double,
+// include/matrix.h:50-53); demod_params (double) widens into this.
+struct Options {
+    long double sample_rate = 125000.L;
+    long double lowpass_in = 0.L;
+    long double lowpass_out = 12500.L;
+    long double epsilon = .3;
+    size_t in_degree = 0;
+    size_t out_degree = 3;
+    unsigned mode = 0x10;
+    size_t buf_size = DEMOD_DEFAULT_BUF_SIZE;
+};
+
+Options options_from_params(const demod_params &p);
+
+enum Conditioning : int { kShiftOrigin = 0, kNormalize = 3 };
+
+struct Stage {
+    int sections = 0;                 // S = ceil(degree / 2)
+    float sos[kMaxSections][6] = {};  // {b0,b1,b2,a0,a1,a2} per section, as the reference stores them
+    int taps = 0;                     // T
+    float h[kMaxTaps] = {};           // look-ahead FIR the sectioned recurrence collapses to
+    float bias_im = 0.f;              // constant the imaginary lane of the complex filter carries
+};
+
+struct Plan {
+    uint64_t chunk_bytes = 0;  // B
+    int conditioning = kShiftOrigin;
+    bool prefilter = false;
+    Stage in;    // complex input filter (-L), sections == 0 when absent
+    Stage out;   // real output filter (-l)
+    int head_outputs = 0;  // H: outputs per chunk that the closed form does not cover
+    int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row that leave their store to the head kernel
+};
+
+// Pre-warped bilinear Butterworth / Chebyshev-I design -> float SOS rows
+// (what processFilterOption leaves in sosf, /root/reference/src/matrix.c:25-80).
+// kind: 0 Butterworth lowpass, 1 Chebyshev-I lowpass, 2 Butterworth highpass,
+// 3 Chebyshev-I highpass.
+void design_sections(unsigned kind, size_t degree, long double fc, long double fs,
+                     long double epsilon, float (*sos)[6]);
+
+// Collapse the sectioned in-place recurrence of applyFilter / applyComplexFilter
+// (src/filter.c:212-259) into the forward-looking FIR it is equivalent to in a
+// chunk interior.
+void derive_taps(Stage &st);
+
+// Validate the option set and build the plan.  Returns false with a message.
+bool build_plan(const Options &o, Plan &plan, std::string &err);
+
+}  // namespace demod

@@ -1,0 +1,222 @@
+"""Demodulator: Python face of the C ABI (include/demod_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native
+from ._native import DemodError, Params, Span
+
+DEFAULT_BUF_SIZE = 262144  # include/matrix.h:37-39
+
+
+@dataclass
+class Options:
+    """The reference's command-line options that reach the hot path, with its
+    defaults (/root/reference/src/main.c:102-113)."""
+
+    sample_rate: float = 125000.0   # -S
+    lowpass_in: float = 0.0         # -L   (0 = no input lowpass)
+    lowpass_out: float = 12500.0    # -l
+    epsilon: float = 0.3            # -e x stores x/10
+    in_degree: int = 0              # -D
+    out_degree: int = 3             # -d
+    mode: int = 0x10                # -m | -q<<2 | -c<<4
+    buf_size: int = DEFAULT_BUF_SIZE  # DEFAULT_BUF_SIZE shifted by -b
+
+    @classmethod
+    def from_cli(cls, S=None, L=None, l=None, D=None, d=None, e=None, m=0, b=0, q=0, c=0):  # noqa: E741
+        """Build options the way main()'s getopt loop does (src/main.c:125-183)."""
+        o = cls()
+        if S is not None:
+            o.sample_rate = float(S)
+        if L is not None:
+            o.lowpass_in = float(L)
+        if l is not None:
+            o.lowpass_out = float(l)
+        if D is not None:
+            o.in_degree = int(D)
+        if d is not None:
+            o.out_degree = int(d)
+        if e is not None:
+            o.epsilon = float(e) / 10.0
+        o.mode |= int(m) | (int(q) << 2) | (int(c) << 4)
+        b = int(b)
+        if abs(b) < 17:
+            o.buf_size = DEFAULT_BUF_SIZE >> -b if b < 1 else DEFAULT_BUF_SIZE << b
+        return o
+
+    def c_struct(self) -> Params:
+        return Params(self.sample_rate, self.lowpass_in, self.lowpass_out, self.epsilon,
+                      self.in_degree, self.out_degree, self.mode, 0, self.buf_size)
+
+
+def design(options: Options, which: str = "out") -> dict:
+    """Host-only filter design (no GPU needed): SOS rows, stencil taps, the
+    imaginary-lane bias and the per-chunk head length for an option set."""
+    lib = _native.load()
+    p = options.c_struct()
+    rows = np.zeros((16, 6), dtype=np.float32)
+    taps = np.zeros(8, dtype=np.float32)
+    bias = C.c_float(0)
+    n_taps = C.c_int(0)
+    head = C.c_int(0)
+    n = lib.demod_design_query(C.byref(p), 1 if which == "in" else 0, rows.ctypes.data, 16,
+                               taps.ctypes.data, 8, C.byref(bias), C.byref(n_taps), C.byref(head))
+    if n < 0:
+        raise DemodError(f"demod_design_query failed ({n}): {lib.demod_last_error(None).decode()}")
+    return {"sos": rows[:n].copy(), "taps": taps[:n_taps.value].copy(), "bias_im": float(bias.value),
+            "head_outputs": int(head.value)}
+
+
+class Demodulator:
+    """One demodulation context on one GPU.
+
+    process()       device tensor in -> device tensor out (the hot path)
+    process_host()  numpy in -> numpy out through the pinned double-buffered path
+    """
+
+    def __init__(self, options: Options | None = None, device: int = 0, **kw):
+        self._lib = _native.load()
+        self.options = options if options is not None else Options(**kw)
+        self.device = int(device)
+        self._ctx = C.c_void_p()
+        p = self.options.c_struct()
+        rc = self._lib.demod_create(C.byref(p), self.device, C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.demod_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise DemodError(f"demod_create failed ({rc}): {msg}")
+
+    # -- lifetime -------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.demod_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise DemodError(f"{what} failed ({rc}): {self._lib.demod_last_error(self._ctx).decode()}")
+
+    # -- introspection ----------------------------------------------------------
+    def sos(self, which: str = "out") -> np.ndarray:
+        w = 1 if which == "in" else 0
+        n = self._lib.demod_get_sos(self._ctx, w, None, 0)
+        rows = np.zeros((max(n, 0), 6), dtype=np.float32)
+        if n > 0:
+            self._lib.demod_get_sos(self._ctx, w, rows.ctypes.data, n)
+        return rows
+
+    def taps(self, which: str = "out"):
+        w = 1 if which == "in" else 0
+        buf = np.zeros(8, dtype=np.float32)
+        bias = C.c_float(0)
+        n = self._lib.demod_get_taps(self._ctx, w, buf.ctypes.data, 8, C.byref(bias))
+        return buf[:max(n, 0)].copy(), float(bias.value)
+
+    @property
+    def head_outputs(self) -> int:
+        return self._lib.demod_get_head_outputs(self._ctx)
+
+    def set_segment_rows(self, rows: int) -> None:
+        self._check(self._lib.demod_set_segment_rows(self._ctx, rows), "demod_set_segment_rows")
+
+    # -- the hot path -----------------------------------------------------------
+    def process_ptr(self, d_in: int, n_bytes: int, d_out: int, stream: int = 0, *,
+                    chunk_offset: int = 0, halo_ptr: int = 0, end_of_stream: bool = True) -> None:
+        """Raw-pointer form of demod_process_device (asynchronous on `stream`)."""
+        span = Span(chunk_offset, halo_ptr or None, 1 if end_of_stream else 0, 0)
+        rc = self._lib.demod_process_device(self._ctx, d_in, n_bytes, d_out, C.byref(span),
+                                            stream or None)
+        self._check(rc, "demod_process_device")
+
+    def process(self, iq, out=None, *, chunk_offset: int = 0, halo=None, end_of_stream: bool = True):
+        """iq: 1-D torch.uint8 CUDA tensor of interleaved I,Q bytes.  Returns a
+        torch.float32 CUDA tensor with iq.numel() // 4 results.  Runs on torch's
+        current stream."""
+        import torch
+
+        if not (iq.is_cuda and iq.dtype == torch.uint8 and iq.is_contiguous()):
+            raise DemodError("process() needs a contiguous CUDA uint8 tensor")
+        n = iq.numel()
+        if out is None:
+            out = torch.empty(n // 4, dtype=torch.float32, device=iq.device)
+        elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+                  and out.numel() >= n // 4):
+            raise DemodError("out must be a contiguous CUDA float32 tensor of numel >= n // 4")
+        halo_ptr = 0
+        if halo is not None:
+            if not (halo.is_cuda and halo.dtype == torch.uint8 and halo.numel() >= _native.HALO_BYTES):
+                raise DemodError(f"halo must be a CUDA uint8 tensor of >= {_native.HALO_BYTES} bytes")
+            halo_ptr = halo.data_ptr()
+        stream = torch.cuda.current_stream(iq.device).cuda_stream
+        self.process_ptr(iq.data_ptr(), n - (n & 3), out.data_ptr(), stream,
+                         chunk_offset=chunk_offset, halo_ptr=halo_ptr, end_of_stream=end_of_stream)
+        return out
+
+    def process_host(self, data: np.ndarray, *, chunk_offset: int = 0, halo: np.ndarray | None = None,
+                     end_of_stream: bool = True) -> np.ndarray:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = data.size - (data.size & 3)
+        out = np.empty(n // 4, dtype=np.float32)
+        hp = None
+        if halo is not None:
+            halo = np.ascontiguousarray(halo, dtype=np.uint8)
+            if halo.size < _native.HALO_BYTES:
+                halo = np.concatenate([halo, np.zeros(_native.HALO_BYTES - halo.size, np.uint8)])
+            hp = halo.ctypes.data
+        span = Span(chunk_offset, hp, 1 if end_of_stream else 0, 0)
+        rc = self._lib.demod_process_host(self._ctx, data.ctypes.data, n, out.ctypes.data, C.byref(span))
+        self._check(rc, "demod_process_host")
+        return out
+
+    # -- helpers ----------------------------------------------------------------
+    def synth_fill(self, dst, first_byte: int, seed: int) -> None:
+        """Fill a CUDA uint8 tensor with the counter-based synthetic IQ stream."""
+        import torch
+
+        stream = torch.cuda.current_stream(dst.device).cuda_stream
+        rc = self._lib.demod_synth_fill(self._ctx, dst.data_ptr(), first_byte, dst.numel(), seed,
+                                        stream or None)
+        self._check(rc, "demod_synth_fill")
+
+    def synchronize(self) -> None:
+        self._check(self._lib.demod_synchronize(self._ctx), "demod_synchronize")
+
+    def enable_timing(self, on: bool = True) -> None:
+        self._lib.demod_enable_timing(self._ctx, 1 if on else 0)
+
+    def kernel_ms(self):
+        """(average fused-kernel milliseconds, launches) since the last call."""
+        n = C.c_int(0)
+        ms = self._lib.demod_kernel_ms(self._ctx, C.byref(n))
+        return float(ms), int(n.value)
+
+    def selftest_atan2(self, y: np.ndarray, x: np.ndarray) -> np.ndarray:
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(y)
+        self._check(self._lib.demod_selftest_atan2(self._ctx, y.ctypes.data, x.ctypes.data,
+                                                   out.ctypes.data, y.size), "demod_selftest_atan2")
+        return out
+
+    def selftest_lane_shift(self, v: np.ndarray, halo: float) -> np.ndarray:
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        out = np.empty(64, dtype=np.float32)
+        self._check(self._lib.demod_selftest_lane_shift(self._ctx, v.ctypes.data, halo,
+                                                        out.ctypes.data), "demod_selftest_lane_shift")
+        return out

@@ -1,0 +1,175 @@
+/*
+ * demod_hip.h -- C ABI of the MI355X-native FM-demodulation hot path.
+ *
+ * This is the drop-in boundary: a shared library (libdemod_hip.so) with plain
+ * pointers and sizes, no C++/torch types.  It replaces the reference's
+ * per-chunk pipeline
+ *
+ *     shiftOrigin -> [applyComplexFilter] -> fmDemod -> applyFilter
+ *     (/root/reference/src/matrix.c:236-273, src/filter.c:212-259)
+ *
+ * and the once-per-run filter design behind it (src/matrix.c:25-80,
+ * src/filter.c:22-210).  The reference's own two-symbol backend boundary
+ * (processMatrix / allocateBuffer, include/matrix.h:59-62) is provided as a
+ * thin adapter over this ABI in demod_backend.h.
+ *
+ * Units: one IQ sample = 2 input bytes (uint8 I, uint8 Q).  4 input bytes
+ * produce 1 float32 output (the discriminator consumes non-overlapping pairs
+ * of complex samples, src/matrix.c:166-175).
+ */
+#ifndef DEMOD_HIP_H
+#define DEMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEMOD_ABI_VERSION 1
+
+/* Default chunk size, bytes (include/matrix.h:37-39). */
+#define DEMOD_DEFAULT_BUF_SIZE 262144u
+
+/* Bytes of look-ahead a shard needs from the stream that follows it when the
+ * shard does not end on a chunk boundary (see demod_span). */
+#define DEMOD_HALO_BYTES 64u
+
+/* Highest supported filter degree (-d / -D). */
+#define DEMOD_MAX_DEGREE 16u
+
+/* Error codes (negative). */
+enum {
+    DEMOD_OK = 0,
+    DEMOD_E_INVAL = -1,     /* bad argument / unsupported option set */
+    DEMOD_E_NODEVICE = -2,  /* no usable HIP device */
+    DEMOD_E_HIP = -3,       /* a HIP runtime call failed (see demod_last_error) */
+    DEMOD_E_NOMEM = -4
+};
+
+/* Options that reach the hot path.  Same meaning and defaults as the fields of
+ * the reference's consumerArgs that processMatrix reads
+ * (include/matrix.h:43-57; defaults src/main.c:102-113). */
+typedef struct demod_params {
+    double sample_rate;   /* -S  default 125000 */
+    double lowpass_in;    /* -L  default 0 = no input (complex) lowpass */
+    double lowpass_out;   /* -l  default 12500 */
+    double epsilon;       /* -e x is stored as x/10; default .3 (Chebyshev only) */
+    uint32_t in_degree;   /* -D  default 0 (= use out_degree when -L is given, src/matrix.c:190-192) */
+    uint32_t out_degree;  /* -d  default 3 */
+    uint32_t mode;        /* ww|dd|qq|ff byte, default 0x10 (src/main.c:112):
+                             bit0 output filter Chebyshev-I, bit1 input filter
+                             Chebyshev-I, bits2-3 IQ conditioning (-q: 0
+                             shiftOrigin, 3 normalizeInput), bits4-5 demod mode */
+    uint32_t reserved;
+    uint64_t buf_size;    /* chunk bytes B (DEFAULT_BUF_SIZE shifted by -b); power of two >= 4 */
+} demod_params;
+
+/* Where a device buffer sits in the stream.  Chunks are the reference's unit
+ * of filtering: every chunk is filtered on its own with zero padding
+ * (src/matrix.c:272), so chunk boundaries are part of the numerical result. */
+typedef struct demod_span {
+    uint64_t chunk_offset;   /* bytes between the start of the enclosing chunk and
+                                the first byte of the buffer; multiple of 1024
+                                (0 = buffer starts on a chunk boundary) */
+    const void *halo;        /* DEVICE pointer to the DEMOD_HALO_BYTES bytes that
+                                follow the buffer in the stream, or NULL.  Only
+                                read when the buffer ends inside a chunk. */
+    uint32_t end_of_stream;  /* 1: the stream ends with this buffer; a trailing
+                                partial chunk of r bytes is filtered as a short
+                                chunk of (r & ~3) bytes.  0: the stream continues
+                                (halo must be given if the end is inside a chunk) */
+    uint32_t reserved;
+} demod_span;
+
+typedef struct demod_ctx demod_ctx;
+
+/* Fill p with the reference's defaults. */
+void demod_default_params(demod_params *p);
+
+/* ABI version of the loaded library. */
+int demod_abi_version(void);
+
+/* Create a context on HIP device `device`: designs the filters on the host,
+ * derives the stencil taps and uploads nothing until the first process call.
+ * Fails with DEMOD_E_INVAL for option sets the reference leaves undefined
+ * (-D without -L, src/matrix.c:227-231) or that are out of scope (-q1, -q2,
+ * demod mode 0), with a message in demod_last_error(NULL). */
+int demod_create(const demod_params *p, int device, demod_ctx **out);
+void demod_destroy(demod_ctx *ctx);
+
+/* Last error text of a context (or of demod_create when ctx == NULL). */
+const char *demod_last_error(const demod_ctx *ctx);
+
+/* HOT PATH.  Demodulate n_bytes of uint8 IQ resident in device memory at d_in
+ * into n_bytes/4 float32 at d_out, asynchronously on `stream` (a hipStream_t
+ * passed as void*, NULL = default stream).  d_in must be 16-byte aligned,
+ * d_out 16-byte aligned, n_bytes a multiple of 4.  span == NULL means: buffer
+ * starts on a chunk boundary and the stream ends with it.
+ * One call = one launch of the fused kernel (+ a small chunk-head launch that
+ * runs beside it). */
+int demod_process_device(demod_ctx *ctx, const void *d_in, uint64_t n_bytes, void *d_out,
+                         const demod_span *span, void *stream);
+
+/* Host-buffer convenience used by the CLI and the backend adapter: uploads
+ * h_in in pieces through pinned staging buffers with hipMemcpyAsync on two
+ * streams, runs the hot path, downloads to h_out; returns when h_out is
+ * complete.  Same span semantics as above (halo is a HOST pointer here). */
+int demod_process_host(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, float *h_out,
+                       const demod_span *span);
+
+/* Pinned host memory (the reference's allocateBuffer hook,
+ * src/matrix.c:282-285 / cuda/matrix.cu:106-109). */
+int demod_alloc_pinned(void **p, size_t len);
+void demod_free_pinned(void *p);
+
+/* Device memory helpers so a C host needs no HIP headers. */
+int demod_alloc_device(demod_ctx *ctx, void **p, size_t len);
+void demod_free_device(demod_ctx *ctx, void *p);
+int demod_copy_to_device(demod_ctx *ctx, void *d_dst, const void *h_src, size_t len);
+int demod_copy_to_host(demod_ctx *ctx, void *h_dst, const void *d_src, size_t len);
+int demod_synchronize(demod_ctx *ctx);
+
+/* Introspection (tests): the designed second-order sections
+ * {b0,b1,b2,a0,a1,a2} as float rows, the stencil taps derived from them and
+ * the per-chunk head length handled by the chunk-head kernel.
+ * which: 0 = output filter, 1 = input filter.  Return the row / tap count. */
+int demod_get_sos(const demod_ctx *ctx, int which, float *rows6, int max_rows);
+int demod_get_taps(const demod_ctx *ctx, int which, float *taps, int max_taps, float *bias_im);
+int demod_get_head_outputs(const demod_ctx *ctx);
+
+/* The same design without a context or a device (host only): fills what is
+ * non-NULL and returns the number of sections of the selected filter, or a
+ * negative error code with the text in demod_last_error(NULL). */
+int demod_design_query(const demod_params *p, int which, float *rows6, int max_rows, float *taps,
+                       int max_taps, float *bias_im, int *n_taps, int *head_outputs);
+
+/* Tuning knob: rows (1 KiB of input each) a wavefront streams through before
+ * it needs a fresh look-ahead; power of two, 0 = automatic. */
+int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows);
+
+/* Counter-based synthetic IQ bytes written straight into device memory
+ * (benchmark input): byte i of stream `seed` is byte
+ * (i & 7) of splitmix64 word (i >> 3).  first_byte and n_bytes multiples of 16. */
+int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes,
+                     uint64_t seed, void *stream);
+
+/* Device self-tests for the GPU test-suite (not on the data path): the
+ * kernel's atan2 on n (y, x) pairs from host arrays, and the wavefront
+ * neighbour exchange (out[i] = in[i + 1], out[63] = halo). */
+int demod_selftest_atan2(demod_ctx *ctx, const float *h_y, const float *h_x, float *h_out,
+                         uint32_t n);
+int demod_selftest_lane_shift(demod_ctx *ctx, const float *h_in64, float halo, float *h_out64);
+
+/* Average duration in milliseconds of the fused kernel over the process calls
+ * issued since the previous call to this function, measured with HIP events
+ * on the stream the kernel was launched on.  Enables event recording on first
+ * use; returns < 0 if nothing was recorded. */
+double demod_kernel_ms(demod_ctx *ctx, int *launches);
+void demod_enable_timing(demod_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMOD_HIP_H */

@@ -1,0 +1,201 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors of the
+compiled reference and against the CPU oracle on seeded inputs.  Tolerances:
+tests/parity.py."""
+import numpy as np
+import pytest
+
+import demodulator_amd as dm
+import oracle
+from parity import compare
+
+pytestmark = pytest.mark.gpu
+
+C2 = dict()
+C3 = dict(lowpass_in=12500.0, lowpass_out=6500.0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return oracle.restatement()
+
+
+def _opts(flags: dict) -> dm.Options:
+    return dm.Options(**{k: flags[k] for k in ("sample_rate", "lowpass_in", "lowpass_out", "epsilon",
+                                               "in_degree", "out_degree", "mode", "buf_size")})
+
+
+def _check(name, got, want, opt):
+    taps = dm.design(opt)["taps"]
+    prefilter = opt.lowpass_in != 0
+    rep = compare(got, want, taps, prefilter)
+    assert rep.ok, f"{name}: {rep}"
+    return rep
+
+
+# -- device self-tests ---------------------------------------------------------
+
+def test_wavefront_neighbour_exchange():
+    with dm.Demodulator(buf_size=4096) as d:
+        v = np.arange(64, dtype=np.float32) * 3 + 1
+        out = d.selftest_lane_shift(v, -77.0)
+        assert np.array_equal(out[:63], v[1:]) and out[63] == -77.0
+
+
+def test_atan2_accuracy_and_signed_zeros():
+    with dm.Demodulator(buf_size=4096) as d:
+        rng = np.random.default_rng(11)
+        n = 1 << 20
+        # integer-valued arguments like the no-L path produces, plus wide-range floats
+        y = np.concatenate([rng.integers(-32768, 32768, n).astype(np.float32),
+                            (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 5, n)).astype(np.float32)])
+        x = np.concatenate([rng.integers(-32768, 32768, n).astype(np.float32),
+                            (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 5, n)).astype(np.float32)])
+        got = d.selftest_atan2(y, x).astype(np.float64)
+        want = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+        err = np.abs(got - want)
+        assert err.max() < 4e-7, err.max()           # ~1.5 ulp at pi
+        # IEEE signed-zero table, SURVEY.md Appendix A.2
+        pz, nz, pi = np.float32(0.0), np.float32(-0.0), np.float32(np.pi)
+        ys = np.array([pz, nz, pz, nz, pz, nz, pz, nz, 1, -1], dtype=np.float32)
+        xs = np.array([pz, pz, nz, nz, -21, -21, 5, 5, pz, nz], dtype=np.float32)
+        g = d.selftest_atan2(ys, xs)
+        w = np.array([pz, nz, pi, -pi, pi, -pi, pz, nz, pi / 2, -pi / 2], dtype=np.float32)
+        assert np.array_equal(g.view(np.uint32)[:8], w.view(np.uint32)[:8]), g
+        assert np.allclose(g[8:], w[8:], atol=2e-7)
+
+
+def test_discriminator_known_answers(golden):
+    """Byte quads of SURVEY.md Appendix A.2 through the whole path with a
+    degree-1 output filter (single tap h0): out = h0 * discriminator."""
+    quads = golden("quads_bytes.npy")
+    want = golden("quads_discriminator.npy")
+    opt = dm.Options(out_degree=1, buf_size=4096)
+    h0 = dm.design(opt)["taps"][0]
+    data = np.full(4096, 127, dtype=np.uint8)
+    # place each quad at output index 8 + i (past the 1-output chunk head)
+    data[32:32 + quads.size] = quads.reshape(-1)
+    with dm.Demodulator(opt) as d:
+        out = d.process_host(data)
+    got = out[8:8 + want.size] / h0
+    assert np.max(np.abs(got - want)) < 6e-7
+    assert np.array_equal(np.sign(got), np.sign(want))  # +-pi and +-0 signs
+
+
+# -- golden vectors of the compiled reference -----------------------------------
+
+def test_golden_streams(manifest, golden):
+    worst = {}
+    for name, case in manifest["streams"].items():
+        opt = _opts(case["flags"])
+        data = oracle.synth_bytes(case["seed"], 0, case["n_chunks"] * opt.buf_size)
+        with dm.Demodulator(opt) as d:
+            got = d.process_host(data)
+        rep = _check(name, got, golden(case["file"]), opt)
+        worst[name] = (rep.max_rel, rep.n_wrap)
+    print({k: v for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0])[:5]})
+
+
+def test_golden_fm_like(manifest, golden):
+    data = golden(manifest["fm_like"]["input"])
+    for key in ("dsd", "multimon"):
+        c = manifest["fm_like"][key]
+        opt = _opts(c["flags"])
+        with dm.Demodulator(opt) as d:
+            got = d.process_host(data)
+        _check(key, got, golden(c["file"]), opt)
+
+
+# -- oracle on seeded inputs ------------------------------------------------------
+
+@pytest.mark.parametrize("flags", [C2, C3], ids=["C2", "C3"])
+@pytest.mark.parametrize("seg", [1, 8, 32, 256])
+def test_device_path_vs_oracle(orc, flags, seg):
+    import torch
+    opt = dm.Options(**flags)
+    n_chunks = 5
+    data = oracle.synth_bytes(0xD3300D02 if not flags else 0xD3300D03, 0, n_chunks * opt.buf_size)
+    want = orc.process(oracle.Flags(**{**opt.__dict__}), data)
+    with dm.Demodulator(opt) as d:
+        d.set_segment_rows(seg)
+        iq = torch.from_numpy(data).cuda()
+        out = d.process(iq)
+        torch.cuda.synchronize()
+        _check(f"seg{seg}", out.cpu().numpy(), want, opt)
+
+
+@pytest.mark.parametrize("flags", [C2, C3], ids=["C2", "C3"])
+def test_edge_bytes_and_constant_inputs(orc, flags):
+    """All-127 (zero signal), all-255 (wrap to -128), all-0, alternating extremes."""
+    opt = dm.Options(buf_size=4096, **flags)
+    pats = [np.full(8192, v, np.uint8) for v in (127, 255, 0, 128)]
+    pats.append(np.tile(np.array([0, 255, 255, 0], np.uint8), 2048))
+    pats.append(np.tile(np.array([127, 127, 122, 124, 130, 127, 120, 127], np.uint8), 1024))
+    with dm.Demodulator(opt) as d:
+        for i, p in enumerate(pats):
+            _check(f"pattern{i}", d.process_host(p), orc.process(oracle.Flags(**opt.__dict__), p), opt)
+
+
+@pytest.mark.parametrize("flags", [C2, C3], ids=["C2", "C3"])
+def test_tail_policy_ragged_lengths(orc, flags):
+    """A trailing partial chunk of r bytes is a short chunk of r & ~3 bytes
+    (deterministic tail policy; the reference's own tail is racy)."""
+    opt = dm.Options(buf_size=16384, **flags)
+    with dm.Demodulator(opt) as d:
+        for extra in (4, 12, 1020, 1024, 1028, 5000, 16380):
+            data = oracle.synth_bytes(77, 0, 2 * opt.buf_size + extra)
+            got = d.process_host(data)
+            want = orc.process(oracle.Flags(**opt.__dict__), data)
+            assert got.size == want.size == (2 * opt.buf_size + extra) // 4
+            _check(f"extra{extra}", got, want, opt)
+        for n in (4, 64, 1000, 1024, 2048 + 16):   # stream shorter than one chunk
+            data = oracle.synth_bytes(78, 0, n)
+            _check(f"short{n}", d.process_host(data), orc.process(oracle.Flags(**opt.__dict__), data), opt)
+        assert d.process_host(np.zeros(0, np.uint8)).size == 0
+
+
+@pytest.mark.parametrize("flags", [C2, C3], ids=["C2", "C3"])
+def test_shards_with_halo_equal_whole_stream(orc, flags):
+    """Cutting the stream at an arbitrary multiple of 1 KiB and handing each
+    shard the 64 bytes that follow it reproduces the unsharded result."""
+    import torch
+    opt = dm.Options(buf_size=16384, **flags)
+    total = 6 * opt.buf_size
+    data = oracle.synth_bytes(99, 0, total)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    iq = torch.from_numpy(data).cuda()
+    with dm.Demodulator(opt) as d:
+        for cuts in ([0, 3 * 1024, total], [0, 16384 + 1024, 5 * 16384 - 2048, total], [0, 2 * 16384, total]):
+            parts = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                last = b == total
+                halo = None if last else iq[b:b + dm.HALO_BYTES].clone()
+                parts.append(d.process(iq[a:b].clone(), chunk_offset=a % opt.buf_size, halo=halo,
+                                       end_of_stream=last))
+            torch.cuda.synchronize()
+            got = torch.cat(parts).cpu().numpy()
+            _check(f"cuts{cuts}", got, want, opt)
+            whole = d.process(iq).cpu().numpy()
+            # sharding must not change a single bit relative to the unsharded GPU run
+            assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
+def test_synth_fill_matches_oracle_stream():
+    import torch
+    with dm.Demodulator(buf_size=4096) as d:
+        buf = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
+        for first in (0, 4096, (1 << 33) + 16):
+            d.synth_fill(buf, first, 0xD3300D04)
+            torch.cuda.synchronize()
+            assert np.array_equal(buf.cpu().numpy(), oracle.synth_bytes(0xD3300D04, first, buf.numel()))
+
+
+def test_linearity_free_property_chunk_independence(orc):
+    """Chunks are independent: permuting whole chunks permutes the outputs."""
+    import torch
+    opt = dm.Options(**C3)
+    data = oracle.synth_bytes(5, 0, 4 * opt.buf_size).reshape(4, -1)
+    with dm.Demodulator(opt) as d:
+        a = d.process(torch.from_numpy(data.reshape(-1)).cuda()).cpu().numpy().reshape(4, -1)
+        perm = [2, 0, 3, 1]
+        b = d.process(torch.from_numpy(data[perm].reshape(-1).copy()).cuda()).cpu().numpy().reshape(4, -1)
+    assert np.array_equal(a[perm].view(np.uint32), b.view(np.uint32))

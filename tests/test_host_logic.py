@@ -1,0 +1,131 @@
+"""CPU-side checks of the product's host logic and of the C-ABI library itself
+(no compute calls -- those need the GPU): the library loads, exports every
+symbol include/demod_hip.h declares, designs the same filters as the reference
+and refuses the option sets the reference leaves undefined."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import demodulator_amd as dm
+from demodulator_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "demod_hip.h")).read()
+    declared = set(re.findall(r"\b(demod_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"demod_params", "demod_span", "demod_ctx"}
+    assert declared, "no declarations parsed"
+    lib = C.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in demod_hip.h but not exported"
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+
+
+def test_backend_library_exports_reference_boundary():
+    path = os.path.join(ROOT, "demodulator_amd", "libdemod_backend.so")
+    if not os.path.exists(path):
+        pytest.skip("libdemod_backend.so not built")
+    lib = C.CDLL(path)
+    # the two symbols of the reference's backend boundary, include/matrix.h:59-62
+    assert hasattr(lib, "processMatrix") and hasattr(lib, "allocateBuffer")
+
+
+def test_abi_struct_sizes():
+    assert C.sizeof(_native.Params) == 56
+    assert C.sizeof(_native.Span) == 24
+    assert _native.load().demod_abi_version() == _native.ABI_VERSION
+
+
+def test_design_matches_reference_sos(manifest):
+    """Product filter design (plan.cpp) == reference's processFilterOption, hex-exact,
+    for the lowpass kinds the path uses (mode bit0/bit1)."""
+    for row in manifest["sos"]:
+        if row["kind"] not in (0, 1):
+            continue
+        deg = row["degree"]
+        # output filter, kind selected by mode bit 0
+        opt = dm.Options(sample_rate=row["fs"], lowpass_out=row["fc"], out_degree=deg,
+                         epsilon=row["epsilon"], mode=0x10 | row["kind"], buf_size=4096)
+        got = dm.design(opt, "out")["sos"]
+        want = np.array([[float.fromhex(v) for v in r] for r in row["sos_hex"]], dtype=np.float32)
+        assert np.array_equal(bits(got), bits(want)), row
+        # input filter, kind selected by mode bit 1
+        opt = dm.Options(sample_rate=row["fs"], lowpass_in=row["fc"], in_degree=deg,
+                         epsilon=row["epsilon"], mode=0x10 | (row["kind"] << 1), buf_size=4096)
+        got = dm.design(opt, "in")["sos"]
+        assert np.array_equal(bits(got), bits(want)), row
+
+
+def test_taps_and_bias_survey_values():
+    # SURVEY.md Appendix A.3 table
+    d = dm.design(dm.Options())
+    assert np.allclose(d["taps"], [1.760042, -0.5457233], rtol=1e-7)
+    assert d["head_outputs"] == 3
+    o = dm.Options(lowpass_in=12500.0, lowpass_out=6500.0)
+    assert np.allclose(dm.design(o)["taps"], [2.3492503, -0.72343695], rtol=1e-7)
+    din = dm.design(o, "in")
+    assert np.allclose(din["taps"], [1.760042, -0.5457233], rtol=1e-7)
+    assert din["bias_im"] == -2.0 and din["head_outputs"] == 6
+    # imaginary-lane bias -1/-2/-5/-10 for 1..4 sections; 1, 2, 3 taps
+    for deg, bias, taps in ((1, -1, 1), (2, -1, 2), (3, -2, 2), (5, -5, 2), (6, -5, 3), (7, -10, 3),
+                            (8, -10, 3)):
+        di = dm.design(dm.Options(lowpass_in=12500.0, in_degree=deg), "in")
+        assert di["bias_im"] == bias and di["taps"].size == taps, (deg, di)
+
+
+def test_taps_reproduce_the_recurrence_in_the_interior():
+    """The stencil derived in plan.cpp, applied with numpy, equals the oracle's
+    literal recurrence away from the chunk head (host logic, not the GPU path)."""
+    import oracle
+    orc = oracle.restatement()
+    rng = np.random.default_rng(3)
+    for deg in range(1, 9):
+        d = dm.design(dm.Options(out_degree=deg, lowpass_out=6500.0))
+        x = rng.uniform(-3.14, 3.14, 4096).astype(np.float32)
+        y = orc.filter_real(x, d["sos"])[:4096]
+        xp = np.concatenate([x, np.zeros(8, np.float32)]).astype(np.float64)
+        model = sum(float(h) * xp[j:j + 4096] for j, h in enumerate(d["taps"]))
+        H = d["head_outputs"]
+        assert np.max(np.abs(model[H:] - y[H:])) < 2e-5 * max(1.0, np.abs(d["taps"]).sum()), deg
+
+
+def test_rejected_option_sets():
+    bad = [
+        dm.Options(in_degree=3),                         # -D without -L (src/matrix.c:227-231)
+        dm.Options(mode=0x14),                           # -q1 correctIq
+        dm.Options(mode=0x18),                           # -q2 highpassDc
+        dm.Options(mode=0x00),                           # demod mode 0
+        dm.Options(out_degree=0),
+        dm.Options(out_degree=17),
+        dm.Options(buf_size=3000),
+    ]
+    for o in bad:
+        with pytest.raises(dm.DemodError):
+            dm.design(o)
+
+
+def test_options_from_cli_matches_getopt_rules():
+    o = dm.Options.from_cli(S=96000, l=6500, L=12500, b=-8, m=3)
+    assert (o.sample_rate, o.lowpass_out, o.lowpass_in) == (96000.0, 6500.0, 12500.0)
+    assert o.buf_size == 1024 and o.mode == 0x13
+    assert dm.Options.from_cli(b=2).buf_size == 262144 << 2
+    assert dm.Options.from_cli(b=17).buf_size == 262144          # |b| >= 17 ignored (src/main.c:166)
+    assert dm.Options.from_cli(e=3).epsilon == pytest.approx(0.3)
+    assert dm.Options.from_cli(q=3).mode == 0x1C
+
+
+def test_context_creation_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dm.DemodError, match="no HIP device"):
+        dm.Demodulator()
