@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native FM-demodulation hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c2|c3]
+
+A "step" is one pass of the hot path (one call of demod_process_device through
+the C ABI: the fused streaming kernel + the chunk-head kernel) over one shard of
+synthetic uint8 IQ that is already resident in HBM.  Metric: IQ Msamples/s of
+input (1 sample = 2 bytes in, 0.5 float32 out), whole job.
+
+Workloads (BASELINE.json / SURVEY.md section 8d):
+    target  2^32 samples per GPU, -L 12500 -l 6500   (north_star target; default)
+    c3      2^30 samples per GPU, -L 12500 -l 6500   (configs[2])
+    c2      2^30 samples per GPU, no -L, default -l  (configs[1])
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run;
+the global stream is cut into N contiguous shards.  By default the cut points
+are NOT chunk boundaries (every shard starts 96 KiB into a 256 KiB chunk), so
+each rank needs the 64 look-ahead bytes that follow its shard: they are
+exchanged every step with RCCL send/recv (torch.distributed P2P, backend
+"nccl" = RCCL over xGMI) inside the timed region.  --aligned cuts at chunk
+boundaries instead (no exchange is needed then, and none is made).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_SAMPLE = 4  # 2 B read + 2 B written
+
+WORKLOADS = {
+    "target": dict(log2_samples=32, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03,
+                   desc="2^32-sample synthetic uint8 IQ per GPU, -L 12500 -l 6500 (both lowpasses)"),
+    "c3": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03,
+               desc="2^30-sample synthetic uint8 IQ per GPU, -L 12500 -l 6500"),
+    "c2": dict(log2_samples=30, flags=dict(), seed=0xD3300D02,
+               desc="2^30-sample synthetic uint8 IQ per GPU, no -L, default -l"),
+}
+PHASE_BYTES = 96 * 1024  # unaligned cut: shards start this far into a chunk
+
+
+def cpu_baseline(sample_log2: int, flags: dict, seed: int) -> dict:
+    """The reference CPU path timed on this host: the reference's own functions
+    compiled from its sources (oracle/_ref, prebuilt) when present, else the
+    restatement.  One compute thread, as the reference runs (src/main.c:67-70)."""
+    import numpy as np
+    import oracle
+
+    n_bytes = 2 << sample_log2
+    data = oracle.synth_bytes(seed, 0, n_bytes)
+    fl = oracle.Flags(**flags)
+    ref = oracle.reference()
+    impl, kind = (ref, "reference") if ref is not None else (oracle.restatement(), "port")
+    impl.process(fl, data[: 4 * fl.buf_size])  # warm up (page in, design)
+    t0 = time.perf_counter()
+    out = impl.process(fl, data)
+    dt = time.perf_counter() - t0
+    assert out.size == n_bytes // 4
+    res = {"value": round((n_bytes / 2) / dt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": kind,
+           "sample": f"2^{sample_log2} samples of the same synthetic stream, same flags, "
+                     f"{n_bytes // fl.buf_size} chunks, {dt:.2f} s"}
+    # chunk-parallel upper bound on all host cores (chunks are independent, src/matrix.c:272)
+    cores = os.cpu_count() or 1
+    orc = oracle.restatement()
+    t0 = time.perf_counter()
+    orc.process(fl, data, threads=cores)
+    dt = time.perf_counter() - t0
+    res["all_cores"] = {"value": round((n_bytes / 2) / dt / 1e6, 2), "cores": cores, "kind": "port"}
+    del np
+    return res
+
+
+def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int, world: int,
+                 aligned: bool, seg_rows: int):
+    wl = WORKLOADS[name]
+    n_bytes = 2 << wl["log2_samples"]  # per GPU
+    opt = dm.Options(**wl["flags"])
+    B = opt.buf_size
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = dm.Demodulator(opt, device=dev.index)
+    if seg_rows:
+        d.set_segment_rows(seg_rows)
+    d.enable_timing(True)
+
+    phase = 0 if (aligned or world == 1) else PHASE_BYTES
+    iq = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev)
+    # shard `rank` of the global stream: global bytes [rank*n_bytes, (rank+1)*n_bytes)
+    d.synth_fill(iq, rank * n_bytes, wl["seed"])
+    halo = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device=dev) if phase else None
+    last = rank == world - 1
+
+    def step():
+        if phase:
+            # RCCL send/recv: my first 64 bytes go to the previous rank, the next rank's come to me
+            ops = []
+            if rank > 0:
+                ops.append(dist.P2POp(dist.isend, iq[: dm.HALO_BYTES], rank - 1))
+            if not last:
+                ops.append(dist.P2POp(dist.irecv, halo, rank + 1))
+            for w in dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+        d.process(iq, out, chunk_offset=phase, halo=None if (last or not phase) else halo,
+                  end_of_stream=last or not phase)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    d.kernel_ms()  # drop warm-up timings
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kms, launches = d.kernel_ms()
+    checksum = float(out[:: max(1, out.numel() // 4096)].double().sum().item())
+    d.close()
+    del iq, out
+    torch.cuda.empty_cache()
+    return dict(dt=dt, kernel_ms=kms, launches=launches, n_bytes=n_bytes, opt=opt, checksum=checksum,
+                phase=phase, chunk=B)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="target")
+    ap.add_argument("--aligned", action="store_true", help="cut shards at chunk boundaries (no halo exchange)")
+    ap.add_argument("--segment-rows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import demodulator_amd as dm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the demodulation path has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+
+    r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
+                     args.segment_rows)
+    dt = r["dt"]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples_per_gpu = r["n_bytes"] // 2
+    total_samples = samples_per_gpu * world * args.steps
+    value = total_samples / dt / 1e6
+    line = {
+        "metric": "IQ Msamples/sec (input) end-to-end demod+filter",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (counter-based splitmix64 uint8 IQ, generated on device)",
+        "config": {
+            "workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}",
+            "samples_per_gpu": samples_per_gpu,
+            "chunk_bytes": r["chunk"],
+            "sharding": ("1 GPU" if world == 1 else
+                         f"{world} contiguous shards, " +
+                         ("chunk-aligned cuts, no exchange" if not r["phase"] else
+                          f"cuts {r['phase']} B into a chunk, 64-byte look-ahead via RCCL send/recv per step")),
+        },
+    }
+    if rank == 0:
+        kms = r["kernel_ms"]
+        algo = ALGO_BYTES_PER_SAMPLE * samples_per_gpu
+        achieved = algo / (kms * 1e-3) if kms > 0 else None
+        line["roofline"] = {
+            "bound": "hbm",
+            "kernel": "demod_rows (fused unpack + complex stencil + discriminator/atan2 + real stencil)",
+            "achieved": round(achieved / 1e9, 1) if achieved else None,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK, 4) if achieved else None,
+            "read_only_frac": round(achieved / 2 / HBM_PEAK, 4) if achieved else None,
+            "algorithmic_bytes_per_launch": algo,
+            "kernel_ms": round(kms, 4),
+            "launches_timed": r["launches"],
+            "traffic": None,
+        }
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tr = json.load(open(tpath)).get(args.workload)
+                if tr:
+                    line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                    line["roofline"]["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
+        line["checksum"] = r["checksum"]
+
+        if world == 1 and not args.no_extra:
+            also = {}
+            for name in ("c3", "c2"):
+                if name == args.workload:
+                    continue
+                x = run_workload(dm, torch, dist, name, max(5, args.steps), 2, 0, 1, True, args.segment_rows)
+                sp = x["n_bytes"] // 2
+                steps = max(5, args.steps)
+                a = ALGO_BYTES_PER_SAMPLE * sp / (x["kernel_ms"] * 1e-3)
+                also[name] = {"workload": WORKLOADS[name]["desc"],
+                              "value": round(sp * steps / x["dt"] / 1e6, 1), "unit": "Msamples/s",
+                              "kernel_ms": round(x["kernel_ms"], 4), "roofline_frac": round(a / HBM_PEAK, 4)}
+            line["also"] = also
+
+        if world == 1 and not args.no_cpu_baseline:
+            wl = WORKLOADS[args.workload]
+            line["cpu_baseline"] = cpu_baseline(27, {**wl["flags"]}, wl["seed"])
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

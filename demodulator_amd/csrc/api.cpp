@@ -48,6 +48,8 @@ struct demod_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
 
+    float *sink = nullptr;  // 1 KiB store sink for chunk-head lanes of the streaming kernel
+
     // scratch for the whole-chunk literal path (chunks < 1 KiB)
     float *tiny_work = nullptr;
     uint64_t tiny_stride = 0;
@@ -140,7 +142,8 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
     if ((e = hipSetDevice(device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipMalloc((void **) &ctx->sink, kRowBytes)) != hipSuccess) {
         std::string msg = std::string("HIP setup failed: ") + hipGetErrorString(e);
         demod_destroy(ctx);
         return create_fail(DEMOD_E_HIP, msg);
@@ -173,6 +176,7 @@ void demod_destroy(demod_ctx *ctx) {
         (void) hipEventDestroy(p.second);
     }
     if (ctx->tiny_work) (void) hipFree(ctx->tiny_work);
+    if (ctx->sink) (void) hipFree(ctx->sink);
     if (ctx->aux) (void) hipStreamDestroy(ctx->aux);
     if (ctx->fork_ev) (void) hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void) hipEventDestroy(ctx->join_ev);
@@ -368,6 +372,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         r.in = d_in;
         r.out = d_out;
         r.halo = (!eos && end_in_chunk != 0) ? halo : nullptr;
+        r.sink = ctx->sink;
         r.phase_rows = (uint32_t) (offset / kRowBytes);
         r.rpc_log2 = rpc_log2;
         r.seg_log2 = seg_log2;

@@ -16,6 +16,7 @@ struct RowLaunch {
     const uint8_t *in;
     float *out;
     const uint8_t *halo;   // DEMOD_HALO_BYTES that follow the buffer in the stream (device), or null
+    float *sink;           // 1 KiB of device scratch that swallows the stores of chunk-head lanes
     uint32_t n_rows;       // rows in the buffer; the last one may be ragged
     uint32_t phase_rows;   // chunk-local row index of buffer row 0
     uint32_t rpc_log2;     // log2(rows per chunk)
