@@ -14,7 +14,7 @@ ARCH    ?= gfx950
 PKG      = demodulator_amd
 SRC      = $(PKG)/csrc
 # -ffp-contract=off: the kernels spell every fused multiply-add explicitly
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall \
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall \
            -Wno-unused-function -Iinclude -I$(SRC)
 CFLAGS   = -O2 -std=gnu99 -Wall -Iinclude
 

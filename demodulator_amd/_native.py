@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdemod_hip.so")
+# DEMOD_HIP_LIBRARY selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("DEMOD_HIP_LIBRARY") or os.path.join(_HERE, "libdemod_hip.so")
 
 ABI_VERSION = 1
 HALO_BYTES = 64

@@ -333,7 +333,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     }
 
     const uint32_t rpc_log2 = log2u(B / kRowBytes);
-    uint32_t seg_log2 = ctx->seg_rows ? log2u(ctx->seg_rows) : 5u;
+    uint32_t seg_log2 = log2u(ctx->seg_rows ? std::min(ctx->seg_rows, max_segment_rows()) : max_segment_rows());
     seg_log2 = std::min(seg_log2, rpc_log2);
 
     // ---- chunk heads (literal replay), beside the streaming kernel --------

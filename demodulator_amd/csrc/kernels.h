@@ -11,6 +11,9 @@ namespace demod {
 constexpr uint32_t kRowBytes = 1024;   // one wavefront row: 64 lanes x 16 B of IQ
 constexpr uint32_t kRowOutputs = 256;  // float32 results per row: 64 lanes x 4
 
+// Largest segment (rows per wavefront) the streaming kernel was built for.
+uint32_t max_segment_rows();
+
 // Main streaming kernel: rows [0, n_rows) of a device buffer.
 struct RowLaunch {
     const uint8_t *in;

@@ -33,15 +33,14 @@ namespace demod {
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef DEMOD_ROWS_IN_FLIGHT
-#define DEMOD_ROWS_IN_FLIGHT 4
+#ifndef DEMOD_ROWS_PER_WAVE
+#define DEMOD_ROWS_PER_WAVE 8
 #endif
-constexpr int kGroup = DEMOD_ROWS_IN_FLIGHT;  // rows in flight per wavefront (ring size)
+constexpr int kGroup = DEMOD_ROWS_PER_WAVE;  // rows (1 KiB each) one wavefront owns and keeps in flight
 
-constexpr float kPi = 3.14159274101257324f;      // (float) pi, what atan2f returns on the negative real axis
-constexpr float kHalfPi = 1.57079637050628662f;  // (float) (pi / 2)
 
 // ---------------------------------------------------------------------------
 // small device helpers
@@ -60,16 +59,43 @@ __device__ __forceinline__ float wave_first(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
+// v_mul_legacy_f32 (0 * x = 0 for every x, infinities included) through its LLVM
+// intrinsic, so that hipcc schedules it and pads its hazards like any other
+// instruction (an inline-asm consumer right behind v_rcp_f32 read a stale value).
+extern "C" __device__ float demod_llvm_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+__device__ __forceinline__ float fmul_legacy(float a, float b) { return demod_llvm_fmul_legacy(a, b); }
+
+// a ? b : c, bit by bit: one v_bitop3_b32 (full-rate on gfx950; v_bfi_b32,
+// v_cndmask_b32, v_min/v_max and v_cmp issue at roughly half that rate --
+// tools/microbench/valu_rate.hip).
+__device__ __forceinline__ uint32_t bit_select(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xCA);
+}
+
 // atan2(y, x) for finite arguments with IEEE signed-zero behaviour:
 //   atan2(+-0, x >= +0) = +-0, atan2(+-0, x <= -0) = +-pi  (SURVEY.md Appendix A.2).
 // Octant reduction to q = min/max in [0, 1], odd minimax polynomial q*P(q^2)
-// (8 coefficients, |error| < 7e-8 before rounding), one v_rcp_f32.
+// (8 coefficients, |error| < 7e-8 before rounding), one v_rcp_f32.  The octant
+// logic is written with sign-bit masks instead of compares and selects so that
+// everything except the reciprocal is a full-rate VALU operation.
 __device__ __forceinline__ float fast_atan2(float y, float x) {
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float hi = fmaxf(fmaxf(ax, ay), FLT_MIN);  // never 0: atan2(0, 0) must come out as 0 or pi
-    const float lo = fminf(ax, ay);
-    const float q = lo * __builtin_amdgcn_rcpf(hi);
+    const uint32_t xb = __float_as_uint(x), yb = __float_as_uint(y);
+    const float t = fabsf(x) - fabsf(y);
+    const uint32_t swap = (uint32_t) (__float_as_int(t) >> 31);  // all ones when |y| > |x|
+    const float hi = fabsf(__uint_as_float(bit_select(swap, yb, xb)));
+    const float lo = fabsf(__uint_as_float(bit_select(swap, xb, yb)));
+    // v_mul_legacy_f32: 0 * anything = 0, so atan2(0, 0) (lo = 0, 1/hi = inf) gives q = 0
+    const float q = fmul_legacy(lo, __builtin_amdgcn_rcpf(hi));
     const float s = q * q;
+#ifdef DEMOD_ATAN_7COEF
+    float p = 6.811792962e-03f;
+    p = fmaf(p, s, -3.360421956e-02f);
+    p = fmaf(p, s, 7.962366939e-02f);
+    p = fmaf(p, s, -1.323334277e-01f);
+    p = fmaf(p, s, 1.980781555e-01f);
+    p = fmaf(p, s, -3.331736922e-01f);
+    p = fmaf(p, s, 9.999961257e-01f);
+#else
     float p = -4.054567311e-03f;
     p = fmaf(p, s, 2.186295763e-02f);
     p = fmaf(p, s, -5.591232702e-02f);
@@ -78,10 +104,15 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
     p = fmaf(p, s, 1.994656622e-01f);
     p = fmaf(p, s, -3.332985938e-01f);
     p = fmaf(p, s, 9.999993443e-01f);
-    float r = p * q;
-    r = ay > ax ? kHalfPi - r : r;
-    r = __float_as_int(x) < 0 ? kPi - r : r;  // sign bit, so -0 counts as negative
-    return copysignf(r, y);
+#endif
+    float r = p * q;                                               // atan(lo / hi) in [0, pi/4]
+    // |y| > |x|:  pi/2 - r  ==  |r - pi/2|
+    r = r - __uint_as_float(swap & 0x3FC90FDBu);
+    // x negative (sign bit, so -0 counts):  pi - r'  ==  |r' - pi|
+    const uint32_t xneg = (uint32_t) ((int32_t) xb >> 31);
+    r = fabsf(r) - __uint_as_float(xneg & 0x40490FDBu);
+    // magnitude of r, sign of y
+    return __uint_as_float(bit_select(0x7FFFFFFFu, __float_as_uint(r), yb));
 }
 
 // Quadrature discriminator of one pair of complex samples z0 = a + ib,
@@ -92,12 +123,21 @@ __device__ __forceinline__ float discriminate(float a, float b, float c, float d
     return fast_atan2(zj, zr);
 }
 
-// Four bytes -> (byte - 127) wrapped to int8, all four at once (SWAR):
-// per byte, ((b | 0x80) - 0x7f) is (b & 0x7f) + 1 with no borrow between bytes;
-// xor with the inverted top bit adds the +128 for b < 128.
+// Four bytes -> (byte + 1) & 255 each, all four at once (SWAR): adding 1 to the
+// low 7 bits of every byte cannot carry into the next byte; the carry into bit 7
+// is folded in with an xor.  (byte + 1) & 255 == (int8_t)(byte - 127) + 128.
 __device__ __forceinline__ uint32_t rebias4(uint32_t w) {
-    const uint32_t q = (w | 0x80808080u) - 0x7F7F7F7Fu;
-    return q ^ (~w & 0x80808080u);
+    const uint32_t t = (w & 0x7F7F7F7Fu) + 0x01010101u;
+    return t ^ (w & 0x80808080u);
+}
+
+// 128.0f that hipcc cannot see through: keeps "(float) byte - 128" a
+// v_cvt_f32_ubyteN and a float subtract instead of integer SDWA arithmetic
+// followed by v_cvt_f32_i32 (both exact; the former is cheaper on gfx950).
+__device__ __forceinline__ float opaque_128() {
+    float k = 128.0f;
+    asm("" : "+v"(k));
+    return k;
 }
 
 template <int COND>
@@ -110,12 +150,17 @@ __device__ __forceinline__ void unpack_dword(uint32_t w, float scale, float &i0,
         i1 = (float) ((w >> 16) & 0xFFu) * scale - 1.0f;
         q1 = (float) (w >> 24) * scale - 1.0f;
     } else {
-        // (int8_t)(byte - 127): 255 -> -128, 127 -> +0 (src/matrix.c:92-96)
+        // (int8_t)(byte - 127): 255 -> -128, 127 -> +0 (src/matrix.c:92-96), as
+        // v_cvt_f32_ubyteN of the re-biased byte minus 128 (both exact).  The
+        // byte-select conversions issue beside the main VALU pipe; the SDWA
+        // sign-extending form costs more than twice a full-rate operation
+        // (tools/microbench/valu_rate.hip).
         const uint32_t u = rebias4(w);
-        i0 = (float) (int8_t) (u & 0xFFu);
-        q0 = (float) (int8_t) ((u >> 8) & 0xFFu);
-        i1 = (float) (int8_t) ((u >> 16) & 0xFFu);
-        q1 = (float) (int8_t) (u >> 24);
+        const float k = opaque_128();
+        i0 = (float) (u & 0xFFu) - k;
+        q0 = (float) ((u >> 8) & 0xFFu) - k;
+        i1 = (float) ((u >> 16) & 0xFFu) - k;
+        q1 = (float) (u >> 24) - k;
     }
 }
 
@@ -213,6 +258,48 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, H
     for (int j = 0; j < TOUT - 1; ++j) halo.d[j] = wave_first(d[j]);
 }
 
+// Look-ahead a segment needs from the row after it: only that row's lane-0
+// values (its first complex samples and first discriminator outputs), which
+// depend on its first lanes alone.  For the common short stencils they depend on
+// lane 0's own 16 bytes, so only that part of the row is computed; the long
+// stencils fall back to a full row (its own look-ahead is irrelevant).
+template <int TIN, int TOUT, int COND>
+__device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunch &a, Halo &halo) {
+    constexpr int ND = TOUT - 1;                        // discriminator outputs to hand back
+    constexpr int NX = 2 * ND + (TIN > 0 ? TIN - 1 : 0);  // complex samples they read
+    if constexpr (NX <= 8 && (TIN > 0 ? TIN - 1 : 0) <= 8) {
+        float xr[8], xi[8];
+        unpack_dword<COND>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+        if constexpr (NX > 2) unpack_dword<COND>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+        if constexpr (NX > 4) unpack_dword<COND>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+        if constexpr (NX > 6) unpack_dword<COND>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            float d;
+            if constexpr (TIN > 0) {
+                const float ar = stencil0<TIN>(a.hin, &xr[2 * j]);
+                const float ai = stencil<TIN>(a.hin, &xi[2 * j], a.bias_im);
+                const float br = stencil0<TIN>(a.hin, &xr[2 * j + 1]);
+                const float bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.bias_im);
+                d = discriminate(ar, ai, br, bi);
+            } else {
+                d = discriminate(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1]);
+            }
+            halo.d[j] = wave_first(d);
+        }
+        if constexpr (TIN > 1) {
+#pragma unroll
+            for (int j = 0; j < TIN - 1; ++j) {
+                halo.xr[j] = wave_first(xr[j]);
+                halo.xi[j] = wave_first(xi[j]);
+            }
+        }
+    } else {
+        float unused[4];
+        process_row<TIN, TOUT, COND, false>(w, a, halo, 16, unused);
+    }
+}
+
 __device__ __forceinline__ uint4 load_row16(const uint8_t *row_base, uint32_t lane) {
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row_base) + lane);
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -228,23 +315,27 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
 }
 
-// Ring-slot load that hipcc does not track (see demod_rows): 16 bytes per lane,
-// non-temporal.  Must be paired with wait_row_load before the first use.
-__device__ __forceinline__ void issue_row_load(u32x4 &dst, const uint8_t *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
-}
-// Wait until at most N vector-memory operations issued after the slot's load
-// are outstanding; names the slot read-write so no use is scheduled above it.
-template <int N>
-__device__ __forceinline__ void wait_row_load(u32x4 &slot) {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "i"(N) : "memory");
+// Result store that hipcc does not count on vmcnt (see demod_rows).  The
+// trailing s_nop keeps the next instruction from overwriting the data registers
+// before the store has read them (nothing inside an asm statement is padded).
+__device__ __forceinline__ void store_out16_uncounted(float *dst, const float (&y)[4]) {
+    f32x4 v;
+    v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
+#ifdef DEMOD_NO_NT
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+#endif
 }
 
 __device__ __forceinline__ void store_out16(float *dst, const float (&y)[4]) {
     f32x4 v;
     v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
+#ifdef DEMOD_NO_NT
+    *reinterpret_cast<f32x4 *>(dst) = v;
+#else
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+#endif
 }
 
 // 16 bytes of a ragged row: only `valid` (multiple of 4) bytes exist.
@@ -293,35 +384,20 @@ __global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
         return load_row16(base, lane);
     };
 
-    // look-ahead for the last row of the segment
     Halo halo;
 #pragma unroll
     for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = halo.d[j] = 0.f;
-    if ((ge & rpc_mask) != 0) {
-        // The segment ends inside a chunk: run the row that follows once, only
-        // for the lane-0 values it hands back (they depend on its first lanes
-        // alone, so the unknown look-ahead of that row itself does not matter).
-        float unused[4];
-        if (re < a.n_rows) {
-            process_row<TIN, TOUT, COND, RAGGED>(load(re), a, halo, lane_valid(re), unused);
-        } else if (a.halo != nullptr) {
-            // the stream continues on another shard: its first DEMOD_HALO_BYTES bytes
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (lane < DEMOD_HALO_BYTES / 16u) w = reinterpret_cast<const uint4 *>(a.halo)[lane];
-            process_row<TIN, TOUT, COND, false>(w, a, halo, 16, unused);
-        }
-        // else: the stream ends here (short final chunk): zeros, as the reference's buffers hold
-    }
 
     if constexpr (RAGGED) {
-        // bounds-checked build (final short chunk only): plain one-row-ahead loop
-        uint4 cur = load(re - 1u);
+        // bounds-checked build (final short chunk only): one row at a time
+        if ((ge & rpc_mask) != 0 && re < a.n_rows) {
+            float unused[4];
+            process_row<TIN, TOUT, COND, true>(load(re), a, halo, lane_valid(re), unused);
+        }
         for (uint32_t r = re; r-- > rb;) {
-            uint4 nxt = cur;
-            if (r > rb) nxt = load(r - 1u);
             float y[4];
             const int valid = lane_valid(r);
-            process_row<TIN, TOUT, COND, true>(cur, a, halo, valid, y);
+            process_row<TIN, TOUT, COND, true>(load(r), a, halo, valid, y);
             const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
             float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
             if (!head) {
@@ -333,60 +409,99 @@ __global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
                         if (4 * j < valid) dst[j] = y[j];
                 }
             }
-            cur = nxt;
         }
     } else {
-        // kGroup rows are in flight per wavefront, each in a fixed set of
-        // registers (a ring slot).  hipcc assumes that loads and stores may
-        // complete out of order when both are pending and drains vmcnt to 0 at
-        // every use; on gfx950 vector-memory operations retire in issue order
-        // (MI355X_MICROARCH.md, s_waitcnt note), so the ring's loads are issued
-        // from inline asm and waited for with exact counts: when slot k is
-        // needed, everything issued after its load may stay in flight -- the
-        // other slots' refills AND all stores.  The loop is straight-line per
-        // group: wait(k), compute, store, refill(k).
-        u32x4 q[kGroup];
+        // A wavefront owns at most kGroup rows (4 KiB by default) and asks for all
+        // of them, plus the row that follows when the segment ends inside a chunk,
+        // before it computes anything: short-lived wavefronts over a compact,
+        // advancing window of memory are what reaches the HBM streaming rate
+        // (tools/microbench/stream_copy.hip: 1-4 rows per wavefront 0.80-0.83 of
+        // peak, 32 rows 0.74, 256 rows 0.65).
+        const bool need_next = (ge & rpc_mask) != 0u;             // segment ends inside a chunk
+        const bool next_in_buffer = need_next && re < a.n_rows;   // ... and the next row is ours to read
+        const bool next_is_halo = need_next && !next_in_buffer && a.halo != nullptr;
+        // The row after the segment is asked for first (it is needed first), from
+        // wherever it lives: this buffer, the next shard's first DEMOD_HALO_BYTES
+        // bytes, or -- at a chunk or stream end, where the reference's buffers hold
+        // zeros -- nowhere (row rb is read instead and the result discarded, so
+        // that the prologue has no branch around a load).
+        const bool have_next = next_in_buffer || next_is_halo;
+        const uint8_t *nbase = next_in_buffer ? a.in + (uint64_t) re * kRowBytes
+                               : next_is_halo ? a.halo
+                                              : a.in + (uint64_t) rb * kRowBytes;
+        const uint32_t nlane = next_is_halo ? (lane < DEMOD_HALO_BYTES / 16u ? lane : 0u) : lane;
+        // only the dwords the look-ahead reads are loaded (a wider load whose
+        // upper registers are dead makes hipcc wait for it before reusing them)
+        uint4 qn = make_uint4(0, 0, 0, 0);
+        {
+            constexpr int nx = 2 * (TOUT - 1) + (TIN > 0 ? TIN - 1 : 0);
+            const uint32_t *np = reinterpret_cast<const uint32_t *>(nbase) + 4u * nlane;
+            if constexpr (nx > 8 || nx > 4) {
+                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(np));
+                qn = make_uint4(v.x, v.y, v.z, v.w);
+            } else if constexpr (nx > 2) {
+                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(np));
+                qn.x = v.x;
+                qn.y = v.y;
+            } else {
+                qn.x = __builtin_nontemporal_load(np);
+            }
+        }
+        uint4 q[kGroup];
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
             const uint32_t row = re >= rb + 1u + (uint32_t) k ? re - 1u - (uint32_t) k : rb;
-            issue_row_load(q[k], a.in + (uint64_t) row * kRowBytes + 16u * lane);
+#if defined(DEMOD_EXP_NOMEM)      // experiment: arithmetic alone (inputs made up from the lane id)
+            q[k] = make_uint4(lane * 2654435761u + row, lane * 40503u + k, lane ^ (row * 97u), lane + 77u * row);
+#else
+            q[k] = load(row);
+#endif
         }
-        uint32_t top = re;  // rows [rb, top) remain
-        bool first = true;
-        while (top > rb) {
-            const bool last = top <= rb + (uint32_t) kGroup;
-            static_for<kGroup>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const bool live = top >= rb + 1u + (uint32_t) k;
-                const uint32_t r = live ? top - 1u - (uint32_t) k : rb;
-                // operations issued after this slot's load: in the first group the
-                // younger preloads and k store/refill pairs; later a full ring of
-                // pairs; in the last group no refills follow the stores
-                if (first) {
-                    if (last) wait_row_load<kGroup - 1>(q[k]);
-                    else wait_row_load<kGroup - 1 + k>(q[k]);
-                } else {
-                    if (last) wait_row_load<2 * (kGroup - 1) - k>(q[k]);
-                    else wait_row_load<2 * (kGroup - 1)>(q[k]);
-                }
+        // every load above is issued before any computing starts (a scheduling
+        // barrier: nothing moves across it; it does not wait for anything)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            Halo h = halo;
+            next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
+#pragma unroll
+            for (int j = 0; j < kMaxTaps - 1; ++j) {
+                halo.xr[j] = have_next ? h.xr[j] : 0.f;
+                halo.xi[j] = have_next ? h.xi[j] : 0.f;
+                halo.d[j] = have_next ? h.d[j] : 0.f;
+            }
+        }
 
-                float y[4];
-                process_row<TIN, TOUT, COND, false>(make_uint4(q[k].x, q[k].y, q[k].z, q[k].w), a, halo, 16, y);
-
-                // The first lanes of a chunk's first row hold outputs that belong
-                // to the chunk-head kernel: their store goes to the sink, so every
-                // slot issues exactly one store (the counts above rely on it).
+        // All rows are computed before any result is stored: while loads are still
+        // pending no store is, so hipcc's exact vmcnt(N) waits for the rows' loads
+        // are also exact for the hardware (it counts loads and stores on one
+        // counter and would otherwise make a row wait for an earlier row's store).
+        float y[kGroup][4];
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const bool live = re >= rb + 1u + (uint32_t) k;  // wave-uniform
+            if (live) {
+#if defined(DEMOD_EXP_COPYONLY)   // experiment: memory pattern alone
+                y[k][0] = __uint_as_float(q[k].x); y[k][1] = __uint_as_float(q[k].y);
+                y[k][2] = __uint_as_float(q[k].z); y[k][3] = __uint_as_float(q[k].w);
+#else
+                process_row<TIN, TOUT, COND, false>(q[k], a, halo, 16, y[k]);
+#endif
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const bool live = re >= rb + 1u + (uint32_t) k;
+            if (live) {
+                const uint32_t r = re - 1u - (uint32_t) k;
+                // the first lanes of a chunk's first row hold outputs that belong to
+                // the chunk-head kernel
                 const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
-                float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
-                dst = (head || !live) ? a.sink + 4u * lane : dst;
-                store_out16(dst, y);
-                if (!last) {
-                    const uint32_t row = top >= rb + 1u + (uint32_t) (k + kGroup) ? r - (uint32_t) kGroup : rb;
-                    issue_row_load(q[k], a.in + (uint64_t) row * kRowBytes + 16u * lane);
-                }
-            });
-            top = last ? rb : top - (uint32_t) kGroup;
-            first = false;
+#if defined(DEMOD_EXP_NOMEM)
+                if (!head && y[k][0] == 123456.789f) store_out16(a.out + 4u * lane, y[k]);  // keeps the results live
+#else
+                if (!head) store_out16(a.out + (uint64_t) r * kRowOutputs + 4u * lane, y[k]);
+#endif
+            }
         }
     }
 }
@@ -610,6 +725,8 @@ int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
 }
 
 }  // namespace
+
+uint32_t max_segment_rows() { return (uint32_t) kGroup; }
 
 int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
