@@ -19,6 +19,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vect
 CFLAGS   = -O2 -std=gnu99 -Wall -Iinclude
 
 all: lib backend cli oracle
+# (oracle is built after backend so that oracle/_ref/demodulator_refhost can link it)
 
 lib: $(PKG)/libdemod_hip.so
 $(PKG)/libdemod_hip.so: $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/plan.cpp $(SRC)/kernels.h \

@@ -20,7 +20,8 @@ ROW_BYTES = 1024
 # every symbol include/demod_hip.h declares
 EXPORTS = (
     "demod_default_params", "demod_abi_version", "demod_create", "demod_destroy",
-    "demod_last_error", "demod_process_device", "demod_process_host", "demod_alloc_pinned",
+    "demod_last_error", "demod_process_device", "demod_process_host", "demod_stream_capacity",
+    "demod_stream_submit", "demod_stream_collect", "demod_alloc_pinned",
     "demod_free_pinned", "demod_alloc_device", "demod_free_device", "demod_copy_to_device",
     "demod_copy_to_host", "demod_synchronize", "demod_get_sos", "demod_get_taps",
     "demod_get_head_outputs", "demod_design_query", "demod_set_segment_rows", "demod_synth_fill",
@@ -77,6 +78,9 @@ def load() -> C.CDLL:
         "demod_last_error": (C.c_char_p, [vp]),
         "demod_process_device": (i32, [vp, vp, u64, vp, C.POINTER(Span), vp]),
         "demod_process_host": (i32, [vp, vp, u64, vp, C.POINTER(Span)]),
+        "demod_stream_capacity": (u64, []),
+        "demod_stream_submit": (i32, [vp, vp, u64, C.POINTER(Span)]),
+        "demod_stream_collect": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "demod_alloc_pinned": (i32, [C.POINTER(vp), C.c_size_t]),
         "demod_free_pinned": (None, [vp]),
         "demod_alloc_device": (i32, [vp, C.POINTER(vp), C.c_size_t]),

@@ -62,6 +62,9 @@ struct demod_ctx {
         float *dst = nullptr;     // where they go
     } slot[2];
     bool slots_ready = false;
+    int submit_slot = 0;   // streaming form: next slot to fill
+    int collect_slot = 0;  // oldest slot not yet collected
+    int in_flight = 0;
 
     bool fail(int code, const char *what, hipError_t e = hipSuccess) {
         char buf[384];
@@ -530,6 +533,58 @@ int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, flo
     }
     for (auto &s : ctx->slot)
         if ((rc = drain_slot(ctx, s))) return rc;
+    return DEMOD_OK;
+}
+
+uint64_t demod_stream_capacity(void) { return kStageBytes; }
+
+int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, const demod_span *span) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (!h_in || n_bytes == 0 || (n_bytes & 3) || n_bytes > kStageBytes) {
+        ctx->fail(DEMOD_E_INVAL, "stream_submit: need 0 < n_bytes <= capacity, multiple of 4");
+        return DEMOD_E_INVAL;
+    }
+    if (ctx->in_flight >= 2) {
+        ctx->fail(DEMOD_E_INVAL, "stream_submit: both staging slots are in flight; collect first");
+        return DEMOD_E_INVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_slots(ctx);
+    if (rc) return rc;
+    demod_ctx::Slot &s = ctx->slot[ctx->submit_slot];
+    demod_span sp{};
+    if (span) sp = *span;
+    else sp.end_of_stream = 1;
+    if (sp.halo) {  // host pointer here: stage it
+        memcpy(s.h_halo, sp.halo, DEMOD_HALO_BYTES);
+        HIP_TRY(ctx, hipMemcpyAsync(s.d_halo, s.h_halo, DEMOD_HALO_BYTES, hipMemcpyHostToDevice, s.stream));
+        sp.halo = s.d_halo;
+    }
+    memcpy(s.h_in, h_in, n_bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, n_bytes, hipMemcpyHostToDevice, s.stream));
+    rc = demod_process_device(ctx, s.d_in, n_bytes, s.d_out, &sp, s.stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, n_bytes, hipMemcpyDeviceToHost, s.stream));
+    s.out_floats = n_bytes / 4;
+    s.dst = nullptr;
+    ctx->submit_slot ^= 1;
+    ctx->in_flight++;
+    return DEMOD_OK;
+}
+
+int demod_stream_collect(demod_ctx *ctx, const float **out, uint64_t *n_floats) {
+    if (!ctx || !out || !n_floats) return DEMOD_E_INVAL;
+    *out = nullptr;
+    *n_floats = 0;
+    if (ctx->in_flight == 0) return DEMOD_OK;  // nothing pending
+    demod_ctx::Slot &s = ctx->slot[ctx->collect_slot];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    *out = static_cast<const float *>(s.h_out);
+    *n_floats = s.out_floats;
+    s.out_floats = 0;
+    ctx->collect_slot ^= 1;
+    ctx->in_flight--;
     return DEMOD_OK;
 }
 

@@ -119,6 +119,18 @@ int demod_process_device(demod_ctx *ctx, const void *d_in, uint64_t n_bytes, voi
 int demod_process_host(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, float *h_out,
                        const demod_span *span);
 
+/* Pipelined form of the host path for a producer/consumer loop (CLI, backend
+ * adapter): submit copies n_bytes (<= demod_stream_capacity()) into a pinned
+ * staging slot and enqueues upload + hot path + download on that slot's stream,
+ * then returns; collect waits for the OLDEST submitted piece and hands out its
+ * results (pinned memory owned by the context, valid until the slot is reused
+ * two submits later).  Two pieces may be in flight: while piece i is on the
+ * GPU the caller can read piece i+1 from its input and write piece i-1 to its
+ * output.  submit returns DEMOD_E_INVAL if both slots are still uncollected. */
+uint64_t demod_stream_capacity(void);
+int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, const demod_span *span);
+int demod_stream_collect(demod_ctx *ctx, const float **out, uint64_t *n_floats);
+
 /* Pinned host memory (the reference's allocateBuffer hook,
  * src/matrix.c:282-285 / cuda/matrix.cu:106-109). */
 int demod_alloc_pinned(void **p, size_t len);

@@ -1,0 +1,86 @@
+"""End-to-end through real pipes (BASELINE config 1, plumbing): the `demod` CLI
+host keeps the reference's -i/-o/-S/-l/-L contract, and the reference's own
+host runs unchanged on this repo's backend adapter (processMatrix /
+allocateBuffer)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import demodulator_amd as dm
+import oracle
+from parity import compare
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMOD = os.path.join(ROOT, "demodulator_amd", "demod")
+REFHOST = os.path.join(ROOT, "oracle", "_ref", "demodulator_refhost")
+
+
+def _run(cmd, data: bytes) -> bytes:
+    r = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout
+
+
+def test_cli_readme_dsd_pipe(manifest, golden):
+    """cat iq.u8 | demod -i - -o - -S96000 -l12500 (README.md:19-24), 16 KiB chunks."""
+    data = golden(manifest["fm_like"]["input"])
+    c = manifest["fm_like"]["dsd"]
+    out = _run([DEMOD, "-i", "-", "-o", "-", "-S96000", "-l12500", "-b", "-4"], data.tobytes())
+    got = np.frombuffer(out, dtype=np.float32)
+    want = golden(c["file"])
+    assert got.size == want.size == data.size // 4      # byte-exact output length
+    opt = dm.Options(**c["flags"])
+    assert compare(got, want, dm.design(opt)["taps"], False).ok
+
+
+def test_cli_readme_multimon_pipe_files(tmp_path, manifest, golden):
+    """File in, file out, both lowpasses (README.md:26-31) + a ragged tail."""
+    data = golden(manifest["fm_like"]["input"])
+    c = manifest["fm_like"]["multimon"]
+    src = tmp_path / "iq.u8"
+    dst = tmp_path / "out.f32"
+    raw = data.tobytes() + bytes(range(200, 241))        # 41 extra bytes: tail of 40 bytes -> 10 outputs
+    src.write_bytes(raw)
+    _run([DEMOD, "-i", str(src), "-o", str(dst), "-S", "96000", "-l", "6500", "-L", "12500", "-b", "-4"], b"")
+    got = np.fromfile(dst, dtype=np.float32)
+    opt = dm.Options(**c["flags"])
+    want = oracle.restatement().process(oracle.Flags(**opt.__dict__), np.frombuffer(raw, np.uint8))
+    assert got.size == want.size == len(raw) // 4
+    assert np.array_equal(want[: data.size // 4].view(np.uint32), golden(c["file"]).view(np.uint32))
+    assert compare(got, want, dm.design(opt)["taps"], True).ok
+
+
+def test_cli_default_chunk_many_chunks():
+    opt = dm.Options()
+    data = oracle.synth_bytes(0xD3300D02, 0, 5 * opt.buf_size + 1000)
+    out = _run([DEMOD, "-i", "-", "-o", "-"], data.tobytes())
+    got = np.frombuffer(out, dtype=np.float32)
+    want = oracle.restatement().process(oracle.Flags(**opt.__dict__), data)
+    assert got.size == want.size
+    assert compare(got, want, dm.design(opt)["taps"], False).ok
+
+
+def test_cli_rejects_undefined_options():
+    r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-D", "3"], input=b"", stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode != 0 and b"-D without -L" in r.stderr
+
+
+def test_reference_host_on_this_backend(manifest, golden):
+    """The reference's own main.c, linked against libdemod_backend.so: same
+    flags, same pipe, results within the stated tolerance of its CPU path."""
+    if not os.path.exists(REFHOST):
+        pytest.skip("oracle/_ref/demodulator_refhost not built (needs /root/reference at build time)")
+    data = golden(manifest["fm_like"]["input"])
+    for key, flags in (("dsd", ["-S96000", "-l12500"]), ("multimon", ["-S96000", "-l6500", "-L12500"])):
+        c = manifest["fm_like"][key]
+        out = _run([REFHOST, "-i", "-", "-o", "-", "-b", "-4"] + flags, data.tobytes())
+        got = np.frombuffer(out, dtype=np.float32)
+        want = golden(c["file"])
+        assert got.size == want.size
+        opt = dm.Options(**c["flags"])
+        assert compare(got, want, dm.design(opt)["taps"], key == "multimon").ok, key

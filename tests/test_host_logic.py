@@ -129,3 +129,18 @@ def test_context_creation_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(dm.DemodError, match="no HIP device"):
         dm.Demodulator()
+
+
+def test_cli_fails_loudly_without_gpu():
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(ROOT, "demodulator_amd", "demod")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    r = subprocess.run([exe, "-i", "-", "-o", "-"], input=b"\x80" * 4096, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode != 0 and b"no ROCm-capable device" in r.stderr   # no silent CPU path
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode != 0                       # argc < 3, src/main.c:122-124
