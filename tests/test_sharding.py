@@ -1,0 +1,95 @@
+"""Multi-GPU path on CPU: the shard plan and the halo exchange (world_size 2 and
+3 over gloo).  The arithmetic of a shard with a halo is covered on the GPU in
+test_gpu_parity.py::test_shards_with_halo_equal_whole_stream; here the plumbing
+around it is checked with the real torch.distributed point-to-point calls."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from demodulator_amd import HALO_BYTES
+from demodulator_amd.sharding import plan_shards, exchange_halo
+
+
+def test_plan_chunk_aligned_needs_no_exchange():
+    B = 262144
+    shards = plan_shards(8 * (1 << 20) * 8, 8, B)
+    assert [s.length for s in shards] == [8 << 20] * 8
+    assert all(s.chunk_offset == 0 and not s.needs_halo and not s.sends_halo for s in shards)
+    assert shards[-1].end_of_stream and not shards[0].end_of_stream
+
+
+def test_plan_unaligned_cuts():
+    B = 16384
+    total = 6 * B + 5000
+    shards = plan_shards(total, 4, B, align=1024)
+    assert shards[0].start == 0 and shards[-1].stop == total
+    for a, b in zip(shards[:-1], shards[1:]):
+        assert a.stop == b.start and a.stop % 1024 == 0
+        assert b.chunk_offset == b.start % B
+        assert a.needs_halo == (a.stop % B != 0) == b.sends_halo
+    # phase: the stream itself starts 3 KiB into a chunk
+    sh = plan_shards(4 * B, 2, B, phase_bytes=3072)
+    assert sh[0].chunk_offset == 3072 and sh[1].chunk_offset == (3072 + sh[1].start) % B
+    assert sh[0].needs_halo and sh[1].sends_halo
+
+
+def test_plan_tiny_chunks_and_degenerate():
+    sh = plan_shards(64 * 100, 3, 64)
+    assert all(s.start % 64 == 0 and not s.needs_halo for s in sh) and sh[-1].stop == 6400
+    sh = plan_shards(1024, 4, 262144)          # fewer rows than ranks: empty shards are legal
+    assert sum(s.length for s in sh) == 1024 and not any(s.needs_halo and s.length == 0 for s in sh)
+    with pytest.raises(ValueError):
+        plan_shards(1 << 20, 2, 16384, phase_bytes=100)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, B, phase, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shards = plan_shards(total, world, B, phase_bytes=phase, align=1024)
+        me = shards[rank]
+        right = shards[rank + 1] if rank + 1 < world else None
+        iq = torch.from_numpy(oracle.synth_bytes(seed, me.start, me.length))
+        halo = torch.zeros(HALO_BYTES, dtype=torch.uint8)
+        for _ in range(3):                      # a few steps, as bench.py does
+            exchange_halo(me, right, iq, halo)
+        dist.barrier()
+        q.put((rank, me, halo.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,phase", [(2, 0), (2, 3072), (3, 1024)])
+def test_halo_exchange_over_gloo(world, phase):
+    B, seed = 16384, 0xD3300D04
+    total = 5 * B + 7 * 1024
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, B, phase, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stream = oracle.synth_bytes(seed, 0, total)
+    for rank, shard, halo in got:
+        if shard.needs_halo:
+            want = stream[shard.stop: shard.stop + HALO_BYTES]
+            assert np.array_equal(halo[: want.size], want), rank
+        else:
+            assert not halo.any()                # untouched: no message was sent to this rank
