@@ -234,6 +234,12 @@ static void fill_stencils(const Plan &pl, RowLaunch &r) {
         r.hout[j] = pl.out.h[j];
     }
     r.bias_im = pl.in.bias_im;
+    {
+        double sum = 0.0;
+        for (int j = 0; j < pl.in.taps; ++j) sum += (double) pl.in.h[j];
+        r.fold_re = (float) (-128.0 * sum);
+        r.fold_im = (float) ((double) pl.in.bias_im - 128.0 * sum);
+    }
     r.scale = (float) (2. / 255.);
 }
 

@@ -28,6 +28,7 @@ struct RowLaunch {
     uint32_t ragged_bytes; // valid bytes of the last row (multiple of 4, < 1024), 0 = full
     float hin[kMaxTaps];
     float bias_im;
+    float fold_re, fold_im;  // constant terms of the complex stencil with the unpack's -128 folded in
     float hout[kMaxTaps];
     float scale;           // normalizeInput: (float)(2./255.)
 };

@@ -36,6 +36,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DEMOD_EXACT_WAITS
+#define DEMOD_EXACT_WAITS 1
+#endif
 #ifndef DEMOD_ROWS_PER_WAVE
 #define DEMOD_ROWS_PER_WAVE 8
 #endif
@@ -140,7 +143,9 @@ __device__ __forceinline__ float opaque_128() {
     return k;
 }
 
-template <int COND>
+// FOLD: hand back (byte + 1) & 255 as a float, i.e. the sample plus 128, and let
+// the complex stencil absorb the -128 in its constant term (see process_row).
+template <int COND, bool FOLD = false>
 __device__ __forceinline__ void unpack_dword(uint32_t w, float scale, float &i0, float &q0, float &i1,
                                              float &q1) {
     if constexpr (COND == kNormalize) {
@@ -156,11 +161,18 @@ __device__ __forceinline__ void unpack_dword(uint32_t w, float scale, float &i0,
         // sign-extending form costs more than twice a full-rate operation
         // (tools/microbench/valu_rate.hip).
         const uint32_t u = rebias4(w);
-        const float k = opaque_128();
-        i0 = (float) (u & 0xFFu) - k;
-        q0 = (float) ((u >> 8) & 0xFFu) - k;
-        i1 = (float) ((u >> 16) & 0xFFu) - k;
-        q1 = (float) (u >> 24) - k;
+        if constexpr (FOLD) {
+            i0 = (float) (u & 0xFFu);
+            q0 = (float) ((u >> 8) & 0xFFu);
+            i1 = (float) ((u >> 16) & 0xFFu);
+            q1 = (float) (u >> 24);
+        } else {
+            const float k = opaque_128();
+            i0 = (float) (u & 0xFFu) - k;
+            q0 = (float) ((u >> 8) & 0xFFu) - k;
+            i1 = (float) ((u >> 16) & 0xFFu) - k;
+            q1 = (float) (u >> 24) - k;
+        }
     }
 }
 
@@ -193,6 +205,15 @@ __device__ __forceinline__ float stencil0(const float *h, const float *v) {
     return acc;
 }
 
+// With the complex input filter and the shiftOrigin unpack, the "- 128" of the
+// unpack is folded into the stencil's constant term:
+//   h0 (u0 - 128) + h1 (u1 - 128) [+ bias] = fma(h1, u1, fma(h0, u0, C)),  C = [bias] - 128 (h0 + h1)
+// (4 fewer VALU operations per output; the different rounding moves the result
+// by less than the reference's own FMA / non-FMA builds differ).
+// Samples past a chunk end are 0.0f in the reference, i.e. 128 in this domain.
+template <int TIN, int COND, bool RAGGED>
+constexpr bool fold_unpack() { return TIN > 0 && COND == kShiftOrigin && !RAGGED; }
+
 // One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
 // `valid` = usable bytes of this lane's 16 (16 unless RAGGED).
 // halo: in  = look-ahead from the following row (lane 0 of it),
@@ -203,10 +224,11 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, H
     constexpr int NX = 8 + (TIN > 0 ? TIN - 1 : 0);
     constexpr int ND = 4 + TOUT - 1;
     float xr[NX], xi[NX];
-    unpack_dword<COND>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
-    unpack_dword<COND>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
-    unpack_dword<COND>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
-    unpack_dword<COND>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+    constexpr bool FOLD = fold_unpack<TIN, COND, RAGGED>();
+    unpack_dword<COND, FOLD>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+    unpack_dword<COND, FOLD>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+    unpack_dword<COND, FOLD>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+    unpack_dword<COND, FOLD>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
     if constexpr (RAGGED) {
         // past the end of a short final chunk the reference's buffers hold 0.0f
 #pragma unroll
@@ -228,8 +250,13 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, H
         float zr[8], zi[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            zr[k] = stencil0<TIN>(a.hin, &xr[k]);
-            zi[k] = stencil<TIN>(a.hin, &xi[k], a.bias_im);
+            if constexpr (FOLD) {
+                zr[k] = stencil<TIN>(a.hin, &xr[k], a.fold_re);
+                zi[k] = stencil<TIN>(a.hin, &xi[k], a.fold_im);
+            } else {
+                zr[k] = stencil0<TIN>(a.hin, &xr[k]);
+                zi[k] = stencil<TIN>(a.hin, &xi[k], a.bias_im);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = discriminate(zr[2 * j], zi[2 * j], zr[2 * j + 1], zi[2 * j + 1]);
@@ -269,18 +296,27 @@ __device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunc
     constexpr int NX = 2 * ND + (TIN > 0 ? TIN - 1 : 0);  // complex samples they read
     if constexpr (NX <= 8 && (TIN > 0 ? TIN - 1 : 0) <= 8) {
         float xr[8], xi[8];
-        unpack_dword<COND>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
-        if constexpr (NX > 2) unpack_dword<COND>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
-        if constexpr (NX > 4) unpack_dword<COND>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
-        if constexpr (NX > 6) unpack_dword<COND>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+        constexpr bool FOLD = fold_unpack<TIN, COND, false>();
+        unpack_dword<COND, FOLD>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+        if constexpr (NX > 2) unpack_dword<COND, FOLD>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+        if constexpr (NX > 4) unpack_dword<COND, FOLD>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+        if constexpr (NX > 6) unpack_dword<COND, FOLD>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
             float d;
             if constexpr (TIN > 0) {
-                const float ar = stencil0<TIN>(a.hin, &xr[2 * j]);
-                const float ai = stencil<TIN>(a.hin, &xi[2 * j], a.bias_im);
-                const float br = stencil0<TIN>(a.hin, &xr[2 * j + 1]);
-                const float bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.bias_im);
+                float ar, ai, br, bi;
+                if constexpr (FOLD) {
+                    ar = stencil<TIN>(a.hin, &xr[2 * j], a.fold_re);
+                    ai = stencil<TIN>(a.hin, &xi[2 * j], a.fold_im);
+                    br = stencil<TIN>(a.hin, &xr[2 * j + 1], a.fold_re);
+                    bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.fold_im);
+                } else {
+                    ar = stencil0<TIN>(a.hin, &xr[2 * j]);
+                    ai = stencil<TIN>(a.hin, &xi[2 * j], a.bias_im);
+                    br = stencil0<TIN>(a.hin, &xr[2 * j + 1]);
+                    bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.bias_im);
+                }
                 d = discriminate(ar, ai, br, bi);
             } else {
                 d = discriminate(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1]);
@@ -417,6 +453,8 @@ __global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
         // advancing window of memory are what reaches the HBM streaming rate
         // (tools/microbench/stream_copy.hip: 1-4 rows per wavefront 0.80-0.83 of
         // peak, 32 rows 0.74, 256 rows 0.65).
+        // a sample past the chunk end: 0.0f, which is 128 where the unpack bias is folded
+        constexpr float kPastEnd = fold_unpack<TIN, COND, false>() ? 128.f : 0.f;
         const bool need_next = (ge & rpc_mask) != 0u;             // segment ends inside a chunk
         const bool next_in_buffer = need_next && re < a.n_rows;   // ... and the next row is ours to read
         const bool next_is_halo = need_next && !next_in_buffer && a.halo != nullptr;
@@ -430,6 +468,72 @@ __global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
                                : next_is_halo ? a.halo
                                               : a.in + (uint64_t) rb * kRowBytes;
         const uint32_t nlane = next_is_halo ? (lane < DEMOD_HALO_BYTES / 16u ? lane : 0u) : lane;
+#if DEMOD_EXACT_WAITS
+        // ---- loads and waits spelled out ------------------------------------
+        // hipcc keeps one vmcnt score for loads and stores together and, with
+        // both kinds pending, drains it to 0 before any use.  Here every row's
+        // result is stored as soon as it is computed (no result buffer: ~30
+        // fewer VGPRs, 8 wavefronts per SIMD) while later rows' loads are still
+        // in flight, so the loads are issued from inline asm (invisible to
+        // hipcc) and waited for by count: gfx950 retires vector-memory
+        // operations in issue order, and when row k is needed exactly
+        // kGroup-1-k younger loads and k stores have been issued after its
+        // load -- kGroup-1 operations for every k.  Requirements kept below:
+        // straight-line code between a load and its wait, exactly one store
+        // per row (head lanes and rows past a clipped segment store to the
+        // scratch sink), wait statements that name the loaded registers.
+        constexpr int nx = 2 * (TOUT - 1) + (TIN > 0 ? TIN - 1 : 0);
+        const uint8_t *np = nbase + 16u * nlane;
+        u32x4 qn4 = {0, 0, 0, 0};
+        u32x2 qn2 = {0, 0};
+        uint32_t qn1 = 0;
+        if constexpr (nx > 4) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(qn4) : "v"(np) : "memory");
+        else if constexpr (nx > 2) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(qn2) : "v"(np) : "memory");
+        else asm volatile("global_load_dword %0, %1, off nt" : "=v"(qn1) : "v"(np) : "memory");
+        u32x4 qa[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const uint32_t row = re >= rb + 1u + (uint32_t) k ? re - 1u - (uint32_t) k : rb;
+            const uint8_t *rp = a.in + (uint64_t) row * kRowBytes + 16u * lane;
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(qa[k]) : "v"(rp) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the look-ahead row was asked for first: kGroup younger loads may stay in flight
+        if constexpr (nx > 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn4) : "i"(kGroup) : "memory");
+        else if constexpr (nx > 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn2) : "i"(kGroup) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn1) : "i"(kGroup) : "memory");
+        {
+            uint4 qn = make_uint4(0, 0, 0, 0);
+            if constexpr (nx > 4) qn = make_uint4(qn4.x, qn4.y, qn4.z, qn4.w);
+            else if constexpr (nx > 2) { qn.x = qn2.x; qn.y = qn2.y; }
+            else qn.x = qn1;
+            Halo h = halo;
+            next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
+#pragma unroll
+            for (int j = 0; j < kMaxTaps - 1; ++j) {
+                halo.xr[j] = have_next ? h.xr[j] : kPastEnd;
+                halo.xi[j] = have_next ? h.xi[j] : kPastEnd;
+                halo.d[j] = have_next ? h.d[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const bool live = re >= rb + 1u + (uint32_t) k;  // wave-uniform
+            const uint32_t r = live ? re - 1u - (uint32_t) k : rb;
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
+            float y[4];
+            process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, halo, 16, y);
+            // the first lanes of a chunk's first row hold outputs that belong to the
+            // chunk-head kernel; rows past a clipped segment are recomputed copies of
+            // row rb: both store to the sink so that the store count stays exact
+            float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
+            if ((((g0 + r) & rpc_mask) == 0u) || !live) {  // wave-uniform, rare
+                const bool to_sink = !live || lane < a.head_quads;
+                dst = to_sink ? a.sink + 4u * lane : dst;
+            }
+            store_out16(dst, y);
+        }
+#else
         // only the dwords the look-ahead reads are loaded (a wider load whose
         // upper registers are dead makes hipcc wait for it before reusing them)
         uint4 qn = make_uint4(0, 0, 0, 0);
@@ -465,8 +569,8 @@ __global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
             next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
 #pragma unroll
             for (int j = 0; j < kMaxTaps - 1; ++j) {
-                halo.xr[j] = have_next ? h.xr[j] : 0.f;
-                halo.xi[j] = have_next ? h.xi[j] : 0.f;
+                halo.xr[j] = have_next ? h.xr[j] : kPastEnd;
+                halo.xi[j] = have_next ? h.xi[j] : kPastEnd;
                 halo.d[j] = have_next ? h.d[j] : 0.f;
             }
         }
@@ -503,6 +607,7 @@ __global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
 #endif
             }
         }
+#endif  // DEMOD_EXACT_WAITS
     }
 }
 

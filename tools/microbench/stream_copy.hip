@@ -58,6 +58,41 @@ template <bool NT> __global__ __launch_bounds__(256) void k_overlap63_chunked(co
     }
 }
 
+// persistent, software-pipelined: every wavefront walks units of U rows at a stride of the
+// whole grid; loads of the next unit are issued before the current one is consumed; stores
+// are uncounted (inline asm) so that hipcc's vmcnt bookkeeping sees only loads
+__device__ __forceinline__ void st_uncounted(u32x4 *p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+template <int U> __global__ __launch_bounds__(256) void k_pipe(const u32x4 *in, u32x4 *out, size_t n_units) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t W = (size_t) gridDim.x * 4;
+    size_t u = (size_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    u32x4 a[U], b[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) a[k] = __builtin_nontemporal_load(in + (u * U + k) * 64 + lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    while (true) {
+        size_t un = u + W < n_units ? u + W : u;
+#pragma unroll
+        for (int k = 0; k < U; ++k) b[k] = __builtin_nontemporal_load(in + (un * U + k) * 64 + lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < U; ++k) { u32x4 v = a[k]; v.x += 1; st_uncounted(out + (u * U + k) * 64 + lane, v); }
+        if (u + W >= n_units) break;
+        u += W;
+        un = u + W < n_units ? u + W : u;
+#pragma unroll
+        for (int k = 0; k < U; ++k) a[k] = __builtin_nontemporal_load(in + (un * U + k) * 64 + lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < U; ++k) { u32x4 v = b[k]; v.x += 1; st_uncounted(out + (u * U + k) * 64 + lane, v); }
+        if (u + W >= n_units) break;
+        u += W;
+    }
+}
+
 // block-cooperative segment: the 4 waves of a block interleave rows of a 4*SEG-row tile
 template <bool NT, int DIR> __global__ __launch_bounds__(256) void k_blockseg(const u32x4 *in, u32x4 *out, size_t n, int seg) {
     const size_t row0 = (size_t) blockIdx.x * 4 * seg;
@@ -95,6 +130,15 @@ int main() {
         const unsigned gc = (unsigned) ((n / 16384 * 261 + 3) / 4);
         timeit("overlap-63 per-chunk tiles default", [&] { hipLaunchKernelGGL(k_overlap63_chunked<false>, dim3(gc), dim3(256), 0, 0, a, b, n); }, bytes);
         timeit("overlap-63 per-chunk tiles nt", [&] { hipLaunchKernelGGL(k_overlap63_chunked<true>, dim3(gc), dim3(256), 0, 0, a, b, n); }, bytes);
+    }
+    for (int bpc : {4, 5, 6, 8}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "pipelined persistent U=4, %d blocks/CU", bpc);
+        timeit(nm, [&] { hipLaunchKernelGGL(k_pipe<4>, dim3(256 * bpc), dim3(256), 0, 0, a, b, n / 64 / 4); }, bytes);
+        snprintf(nm, sizeof nm, "pipelined persistent U=2, %d blocks/CU", bpc);
+        timeit(nm, [&] { hipLaunchKernelGGL(k_pipe<2>, dim3(256 * bpc), dim3(256), 0, 0, a, b, n / 64 / 2); }, bytes);
+        snprintf(nm, sizeof nm, "pipelined persistent U=1, %d blocks/CU", bpc);
+        timeit(nm, [&] { hipLaunchKernelGGL(k_pipe<1>, dim3(256 * bpc), dim3(256), 0, 0, a, b, n / 64); }, bytes);
     }
     for (int seg : {1, 2, 4}) {
         char nm[96];
