@@ -14,7 +14,11 @@ ARCH    ?= gfx950
 PKG      = demodulator_amd
 SRC      = $(PKG)/csrc
 # -ffp-contract=off: the kernels spell every fused multiply-add explicitly
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall \
+# -fno-slp-vectorize: v_pk_*_f32 issue at half rate on gfx950, packing only adds moves
+# max-ilp scheduling: interleaves the four independent atan2 chains of a row
+# (tools/microbench/valu_rate.hip, profiles/)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize \
+           -mllvm -amdgpu-sched-strategy=max-ilp -fPIC -Wall \
            -Wno-unused-function -Iinclude -I$(SRC)
 CFLAGS   = -O2 -std=gnu99 -Wall -Iinclude
 

@@ -388,8 +388,11 @@ __device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint
 // ---------------------------------------------------------------------------
 // the fused streaming kernel
 // ---------------------------------------------------------------------------
+#ifndef DEMOD_MIN_WAVES_PER_SIMD
+#define DEMOD_MIN_WAVES_PER_SIMD 1
+#endif
 template <int TIN, int TOUT, int COND, bool RAGGED>
-__global__ __launch_bounds__(256) void demod_rows(const RowLaunch a) {
+__global__ __launch_bounds__(256, DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t seg = blockIdx.x * 4u + wave;

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 SRC=demodulator_amd/csrc
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Iinclude -I$SRC -shared"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp -fPIC -Iinclude -I$SRC -shared"
 mkdir -p demodulator_amd/variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
