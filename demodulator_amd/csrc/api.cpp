@@ -151,8 +151,13 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
         demod_destroy(ctx);
         return create_fail(DEMOD_E_HIP, msg);
     }
-    const char *inl = getenv("DEMOD_HEADS_INLINE");
-    ctx->heads_inline = inl && inl[0] == '1';
+    // The chunk-head kernel is independent of the streaming kernel (disjoint
+    // outputs) and can run beside it on the auxiliary stream, but measured on
+    // MI355X the overlap slows the streaming kernel by more (3-4 %) than the head
+    // kernel costs alone (~45 us per 32768 chunks), so it runs in line, first.
+    // DEMOD_HEADS_FORK=1 restores the forked form.
+    const char *fork = getenv("DEMOD_HEADS_FORK");
+    ctx->heads_inline = !(fork && fork[0] == '1');
     *out = ctx;
     return DEMOD_OK;
 }

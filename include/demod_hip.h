@@ -107,8 +107,8 @@ const char *demod_last_error(const demod_ctx *ctx);
  * passed as void*, NULL = default stream).  d_in must be 16-byte aligned,
  * d_out 16-byte aligned, n_bytes a multiple of 4.  span == NULL means: buffer
  * starts on a chunk boundary and the stream ends with it.
- * One call = one launch of the fused kernel (+ a small chunk-head launch that
- * runs beside it). */
+ * One call = one launch of the fused kernel preceded by a small chunk-head
+ * launch on the same stream. */
 int demod_process_device(demod_ctx *ctx, const void *d_in, uint64_t n_bytes, void *d_out,
                          const demod_span *span, void *stream);
 
