@@ -22,6 +22,7 @@
 //   chunk loop     src/matrix.c:236-273
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 
@@ -609,8 +610,15 @@ constexpr int kHeadMaxOut = 32;                                  // ceil4(max(2*
 constexpr int kHeadMaxD = kHeadMaxOut + kMaxSections + 2;        // discriminator values needed
 constexpr int kHeadMaxZ = 2 * kHeadMaxD + 2 * kMaxSections + 2;  // complex cells simulated
 
-template <int COND>
+// SI / SO >= 0: section counts fixed at compile time -- every loop unrolls and
+// every array lives in registers (the designs the CLI defaults produce);
+// SI = SO = -1: any section count up to kMaxSections, arrays in scratch.
+template <int COND, int SI, int SO>
 __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
+    constexpr bool kFixed = SI >= 0;
+    constexpr int kH = kFixed ? 4 * (((2 * SO - 1 > 4 * SI - 2 ? 2 * SO - 1 : 4 * SI - 2) + 3) / 4) : kHeadMaxOut;
+    constexpr int kD = kFixed ? kH + SO + 2 : kHeadMaxD;                    // d[0..W], W = H + So + 1
+    constexpr int kZ = kFixed ? 2 * (kH + SO + 1) + 2 * SI + 2 : kHeadMaxZ;  // complex cells simulated
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.n_heads) return;
     const uint8_t *bytes = a.in + (uint64_t) c * a.chunk_bytes;
@@ -618,12 +626,13 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
     const uint32_t chunk = (c == a.n_heads - 1) ? a.last_chunk_bytes : (uint32_t) a.chunk_bytes;
     const int K = (int) (chunk >> 1);   // complex samples in this chunk
     const int Ld = (int) (chunk >> 2);  // outputs of this chunk
-    const int Si = a.sec_in, So = a.sec_out;
-    const int H = (int) a.head_outputs;
+    const int Si = kFixed ? SI : a.sec_in, So = kFixed ? SO : a.sec_out;
+    const int H = kFixed ? kH : (int) a.head_outputs;
     const int W = H + So + 1;           // discriminator values d[0..W) feed outputs [0, H)
 
-    float d[kHeadMaxD];
-    float yc[kHeadMaxD + 1];
+    float d[kD];
+    float yc[kD + 1];
+#pragma unroll
     for (int n = 0; n <= W; ++n) yc[n] = 0.f;
 
     auto sample = [&](int k, int lane01) -> float {  // unpacked input, 0.0f past the chunk
@@ -632,10 +641,13 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
 
     if (Si > 0) {
         // complex stage, src/filter.c:242-258, cells [0, NZ) brought to their final value
-        float zr[kHeadMaxZ], zi[kHeadMaxZ];
+        float zr[kZ], zi[kZ];
         const int NZ = 2 * W;
+#pragma unroll
         for (int k = 0; k < NZ + 2 * Si + 2; ++k) zr[k] = zi[k] = 0.f;
+#pragma unroll
         for (int i = 0; i + Si < NZ; ++i) {  // iteration i finalises cell i + Si
+#pragma unroll
             for (int m = 0; m < Si; ++m) {
                 const int n = i + Si + m;
                 const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
@@ -648,28 +660,34 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
         }
         // cells K .. K+2Si-2 overflow into the output stage's buffer.  Their
         // "input" is the aliased head of the complex stage's own output
-        // (x[K + t] == z[t]); the last 2Si-1 iterations write them.
-        float ovr[2 * kMaxSections + 1], ovi[2 * kMaxSections + 1];
+        // (x[K + t] == z[t]); the last 2Si-1 iterations (u = 0 .. 2Si-2) write them.
+        float ovr[2 * (kFixed ? SI : kMaxSections) + 1], ovi[2 * (kFixed ? SI : kMaxSections) + 1];
+#pragma unroll
         for (int t = 0; t <= 2 * Si; ++t) ovr[t] = ovi[t] = 0.f;
-        for (int i = K - 2 * Si + 1; i < K; ++i) {
+#pragma unroll
+        for (int u = 0; u < 2 * Si - 1; ++u) {  // iteration K - 2Si + 1 + u
+#pragma unroll
             for (int m = 0; m < Si; ++m) {
-                const int t = i + Si + m - K;
+                const int t = u + 1 - Si + m;  // cell K + t
                 if (t < 0) continue;
                 const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
                 const float a0 = a.sos_in[m][3], a1 = a.sos_in[m][4], a2 = a.sos_in[m][5];
-                float u = b0 * ovr[t] + b1 * ovr[t + 1] + 1.0f;
-                ovr[t] = u - (a0 + a1 * zr[t] + a2 * zr[t + 1]);
-                u = b0 * ovi[t] + b1 * ovi[t + 1];
-                ovi[t] = u - (a0 + a1 * zi[t] + a2 * zi[t + 1]);
+                float v = b0 * ovr[t] + b1 * ovr[t + 1] + 1.0f;
+                ovr[t] = v - (a0 + a1 * zr[t] + a2 * zr[t + 1]);
+                v = b0 * ovi[t] + b1 * ovi[t + 1];
+                ovi[t] = v - (a0 + a1 * zi[t] + a2 * zi[t + 1]);
             }
         }
+#pragma unroll
         for (int t = 0; t < 2 * Si - 1; ++t) {
             if (2 * t <= W) yc[2 * t] = ovr[t];
             if (2 * t + 1 <= W) yc[2 * t + 1] = ovi[t];
         }
+#pragma unroll
         for (int n = 0; n < W; ++n)
             d[n] = n < Ld ? discriminate(zr[2 * n], zi[2 * n], zr[2 * n + 1], zi[2 * n + 1]) : 0.f;
     } else {
+#pragma unroll
         for (int n = 0; n < W; ++n)
             d[n] = n < Ld ? discriminate(sample(2 * n, 0), sample(2 * n, 1), sample(2 * n + 1, 0),
                                          sample(2 * n + 1, 1))
@@ -678,7 +696,10 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
     d[W] = 0.f;  // never reaches an output below H; keeps the window reads defined
 
     // real stage, src/filter.c:221-230: iteration i finalises cell i + So
-    for (int i = 0; i + So < H && i < Ld; ++i) {
+#pragma unroll
+    for (int i = 0; i + So < H; ++i) {
+        if (i >= Ld) break;
+#pragma unroll
         for (int m = 0; m < So; ++m) {
             const int n = i + So + m;
             const float b0 = a.sos_out[m][0], b1 = a.sos_out[m][1];
@@ -687,6 +708,7 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
             yc[n] = t - (a0 + a1 * d[n] + a2 * d[n + 1]);
         }
     }
+#pragma unroll
     for (int n = 0; n < H; n += 4)
         *reinterpret_cast<float4 *>(out + n) = make_float4(yc[n], yc[n + 1], yc[n + 2], yc[n + 3]);
 }
@@ -832,14 +854,35 @@ int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning,
     return launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s);
 }
 
+namespace {
+template <int COND>
+void launch_heads_c(const HeadLaunch &a, hipStream_t s) {
+    const uint32_t blocks = (a.n_heads + 63u) / 64u;
+    const int want_h = 4 * ((std::max(2 * a.sec_out - 1, 4 * a.sec_in - 2) + 3) / 4);
+    const bool std_window = (int) a.head_outputs == want_h;
+#define DEMOD_HEADS_CASE(SI, SO)                                                                   \
+    if (std_window && a.sec_in == SI && a.sec_out == SO) {                                         \
+        hipLaunchKernelGGL((demod_heads<COND, SI, SO>), dim3(blocks), dim3(64), 0, s, a);          \
+        return;                                                                                    \
+    }
+    DEMOD_HEADS_CASE(0, 1)
+    DEMOD_HEADS_CASE(0, 2)
+    DEMOD_HEADS_CASE(1, 1)
+    DEMOD_HEADS_CASE(1, 2)
+    DEMOD_HEADS_CASE(2, 1)
+    DEMOD_HEADS_CASE(2, 2)
+#undef DEMOD_HEADS_CASE
+    hipLaunchKernelGGL((demod_heads<COND, -1, -1>), dim3(blocks), dim3(64), 0, s, a);
+}
+}  // namespace
+
 int launch_heads(const HeadLaunch &a, int conditioning, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.n_heads == 0 || a.head_outputs == 0) return 0;
-    const uint32_t blocks = (a.n_heads + 63u) / 64u;
     if (conditioning == kNormalize)
-        hipLaunchKernelGGL(demod_heads<kNormalize>, dim3(blocks), dim3(64), 0, s, a);
+        launch_heads_c<kNormalize>(a, s);
     else
-        hipLaunchKernelGGL(demod_heads<kShiftOrigin>, dim3(blocks), dim3(64), 0, s, a);
+        launch_heads_c<kShiftOrigin>(a, s);
     return hip_ok(hipGetLastError());
 }
 
