@@ -41,6 +41,7 @@ struct demod_ctx {
     hipStream_t aux = nullptr;  // chunk-head kernel runs here, beside the streaming kernel
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     bool heads_inline = false;
+    bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
     uint32_t seg_rows = 0;  // 0 = automatic
 
     // kernel timing (HIP events on the launch stream)
@@ -201,6 +202,12 @@ int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows) {
     return DEMOD_OK;
 }
 
+int demod_set_seamless(demod_ctx *ctx, int on) {
+    if (!ctx) return DEMOD_E_INVAL;
+    ctx->seamless = on != 0;
+    return DEMOD_OK;
+}
+
 void demod_enable_timing(demod_ctx *ctx, int on) {
     if (ctx) ctx->timing = on != 0;
 }
@@ -293,14 +300,24 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     float *d_out = static_cast<float *>(d_out_v);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const Plan &pl = ctx->plan;
-    const uint64_t B = pl.chunk_bytes;
+    // seamless mode: one chunk as long as any stream (2 TiB); only whether the
+    // buffer starts the stream matters, so a non-zero offset is normalised to
+    // one segment's worth of rows
+    const uint64_t B = ctx->seamless ? (1ull << 41) : pl.chunk_bytes;
 
     if (!d_in || !d_out || (n_bytes & 3) || ((uintptr_t) d_in & 15) || ((uintptr_t) d_out & 15)) {
         ctx->fail(DEMOD_E_INVAL, "buffers must be non-null and 16-byte aligned, n_bytes a multiple of 4");
         return DEMOD_E_INVAL;
     }
-    const uint64_t offset = span ? span->chunk_offset : 0;
+    uint64_t offset = span ? span->chunk_offset : 0;
     const bool eos = span ? span->end_of_stream != 0 : true;
+    if (ctx->seamless) {
+        if (offset & (kRowBytes - 1)) {
+            ctx->fail(DEMOD_E_INVAL, "chunk_offset must be a multiple of 1024");
+            return DEMOD_E_INVAL;
+        }
+        offset = offset ? (uint64_t) max_segment_rows() * kRowBytes : 0;
+    }
     const uint8_t *halo = span ? static_cast<const uint8_t *>(span->halo) : nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -366,7 +383,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         const uint64_t last_len = row_bytes - (first_head + (uint64_t) (n_heads - 1) * B);
         // a last chunk that continues past the buffer is a full chunk for the
         // head window; only a stream end makes it short
-        h.last_chunk_bytes = (uint32_t) ((eos && last_len < B) ? last_len : B);
+        h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
         fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale);
         if (forked) {
             HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, stream));
@@ -395,12 +412,17 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
 
         const uint32_t ragged = (uint32_t) (row_bytes & (kRowBytes - 1));
         const uint32_t total_rows = (uint32_t) ((row_bytes + kRowBytes - 1) / kRowBytes);
-        // rows of the final short chunk (the only place a ragged row can be)
-        // run as their own launch of the bounds-checked build
+        // A ragged last row (stream end only) runs in the bounds-checked build,
+        // together with at most two segments before it; everything ahead of
+        // that split runs in the fast build and may look ahead into the first
+        // row after the split, which is a full row.
         uint32_t split = total_rows;
         if (ragged) {
-            const uint64_t last_chunk_start = row_bytes - std::min<uint64_t>(end_in_chunk, row_bytes);
-            split = (uint32_t) (last_chunk_start / kRowBytes);
+            const uint32_t seg = 1u << seg_log2;
+            const uint32_t phase = (uint32_t) (offset / kRowBytes);
+            const uint32_t keep = total_rows >= 2 ? total_rows - 2 : 0;       // last full row index, at most
+            const uint32_t g = (phase + keep) / seg * seg;                    // segment boundary at or below it
+            split = g > phase ? g - phase : 0;
         }
         std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
         if (ctx->timing) {
@@ -416,6 +438,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         if (split) {
             RowLaunch a = r;
             a.n_rows = split;
+            a.rows_readable = ragged ? split + 1 : split;
             a.ragged_bytes = 0;
             if (ragged) a.halo = nullptr;
             if (launch_rows(a, pl.in.taps, pl.out.taps, pl.conditioning, stream)) {
@@ -428,6 +451,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             a.in = d_in + (uint64_t) split * kRowBytes;
             a.out = d_out + (uint64_t) split * kRowOutputs;
             a.n_rows = total_rows - split;
+            a.rows_readable = a.n_rows;
             a.phase_rows = (uint32_t) (((offset + (uint64_t) split * kRowBytes) % B) / kRowBytes);
             a.ragged_bytes = ragged;
             a.halo = nullptr;
@@ -490,7 +514,7 @@ int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, flo
     if (rc) return rc;
 
     const uint8_t *h_in = static_cast<const uint8_t *>(h_in_v);
-    const uint64_t B = ctx->plan.chunk_bytes;
+    const uint64_t B = ctx->seamless ? (1ull << 41) : ctx->plan.chunk_bytes;
     const uint64_t offset0 = span ? span->chunk_offset : 0;
     const bool eos = span ? span->end_of_stream != 0 : true;
     const uint8_t *tail_halo = span ? static_cast<const uint8_t *>(span->halo) : nullptr;

@@ -67,6 +67,13 @@ void *processMatrix(void *ctx) {
     demod_ctx *dm = NULL;
     const size_t chunk = args->bufSize; /* B, before the producer starts overwriting it */
     int pending = 0;
+    /* DEMOD_SEAMLESS=1: filter the stream as one chunk (demod_set_seamless); not reference behaviour */
+    const char *env_seamless = getenv("DEMOD_SEAMLESS");
+    const int seamless = env_seamless && env_seamless[0] == '1' && chunk >= 1024;
+    unsigned char *held = NULL; /* seamless: the hand-off waiting for its look-ahead */
+    size_t held_n = 0;
+    uint64_t stream_pos = 0;
+    unsigned char halo[DEMOD_HALO_BYTES];
 
     demod_default_params(&p);
     p.sample_rate = (double) args->sampleRate;
@@ -79,6 +86,12 @@ void *processMatrix(void *ctx) {
     p.buf_size = chunk;
     if (demod_create(&p, 0, &dm) != DEMOD_OK) die("cannot start the MI355X demodulation path", demod_last_error(NULL));
     if (chunk > demod_stream_capacity()) die("chunk size", "larger than the staging capacity of the streaming host path");
+
+    if (seamless) {
+        if (demod_set_seamless(dm, 1) != DEMOD_OK) die("seamless", demod_last_error(dm));
+        held = malloc(chunk ? chunk : 1);
+        if (!held) die("malloc", "out of memory");
+    }
 
     for (;;) {
         size_t n;
@@ -95,22 +108,63 @@ void *processMatrix(void *ctx) {
         flag = args->exitFlag;
         if (n > chunk) n = chunk;
         n &= ~(size_t) 3;
-        /* copy out under the mutex, as the protocol requires: submit copies the
-         * bytes into a pinned staging slot and enqueues upload, kernel and
-         * download on that slot's stream without waiting for them.  Every
-         * hand-off is a chunk of its own: a short one (end of input) is
-         * filtered as a short chunk. */
-        if (n && demod_stream_submit(dm, args->buf, n, NULL) != DEMOD_OK) {
-            pthread_mutex_unlock(&args->mutex);
-            die("submit", demod_last_error(dm));
+        if (!seamless) {
+            /* copy out under the mutex, as the protocol requires: submit copies the
+             * bytes into a pinned staging slot and enqueues upload, kernel and
+             * download on that slot's stream without waiting for them.  Every
+             * hand-off is a chunk of its own: a short one (end of input) is
+             * filtered as a short chunk. */
+            if (n && demod_stream_submit(dm, args->buf, n, NULL) != DEMOD_OK) {
+                pthread_mutex_unlock(&args->mutex);
+                die("submit", demod_last_error(dm));
+            }
+            if (n) ++pending;
+        } else {
+            /* seamless: a hand-off can only be filtered once the first bytes of
+             * the next one are known (they are its look-ahead), so it is held
+             * back by one hand-off; the last one ends the stream. */
+            if (held_n) {
+                demod_span sp;
+                memset(&sp, 0, sizeof sp);
+                sp.chunk_offset = stream_pos;
+                sp.end_of_stream = n ? 0 : 1;
+                if (n) {
+                    memset(halo, 0, sizeof halo);
+                    memcpy(halo, args->buf, n < sizeof halo ? n : sizeof halo);
+                    sp.halo = halo;
+                }
+                if (demod_stream_submit(dm, held, held_n, &sp) != DEMOD_OK) {
+                    pthread_mutex_unlock(&args->mutex);
+                    die("submit", demod_last_error(dm));
+                }
+                ++pending;
+                stream_pos += held_n;
+                held_n = 0;
+            }
+            if (n) {
+                memcpy(held, args->buf, n);
+                held_n = n;
+            }
         }
         pthread_mutex_unlock(&args->mutex);
         sem_post(args->empty);
-        if (n) ++pending;
         if (flag) break;
+    }
+    if (seamless && held_n) { /* the stream's last hand-off */
+        demod_span sp;
+        memset(&sp, 0, sizeof sp);
+        sp.chunk_offset = stream_pos;
+        sp.end_of_stream = 1;
+        if (pending == 2) {
+            drain(dm, args->outFile);
+            --pending;
+        }
+        if (demod_stream_submit(dm, held, held_n, &sp) != DEMOD_OK) die("submit", demod_last_error(dm));
+        ++pending;
     }
     while (pending--) drain(dm, args->outFile);
     fflush(args->outFile);
+    free(held);
     demod_destroy(dm);
     return NULL;
 }

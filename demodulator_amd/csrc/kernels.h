@@ -20,7 +20,8 @@ struct RowLaunch {
     float *out;
     const uint8_t *halo;   // DEMOD_HALO_BYTES that follow the buffer in the stream (device), or null
     float *sink;           // 1 KiB of device scratch that swallows the stores of chunk-head lanes
-    uint32_t n_rows;       // rows in the buffer; the last one may be ragged
+    uint32_t n_rows;       // rows this launch computes; the last one may be ragged
+    uint32_t rows_readable; // rows that exist at `in` (>= n_rows): a launch may look ahead into the row after its last
     uint32_t phase_rows;   // chunk-local row index of buffer row 0
     uint32_t rpc_log2;     // log2(rows per chunk)
     uint32_t seg_log2;     // log2(rows per wavefront segment), <= rpc_log2

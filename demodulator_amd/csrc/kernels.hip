@@ -218,7 +218,7 @@ __device__ __forceinline__ float stencil0(const float *h, const float *v) {
 // by less than the reference's own FMA / non-FMA builds differ).
 // Samples past a chunk end are 0.0f in the reference, i.e. 128 in this domain.
 template <int TIN, int COND, bool RAGGED>
-constexpr bool fold_unpack() { return TIN > 0 && COND == kShiftOrigin && !RAGGED; }
+constexpr bool fold_unpack() { return TIN > 0 && COND == kShiftOrigin; }  // every build: results must not depend on which one ran
 
 // One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
 // `valid` = usable bytes of this lane's 16 (16 unless RAGGED).
@@ -240,8 +240,8 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, H
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const bool ok = 2 * k < valid;
-            xr[k] = ok ? xr[k] : 0.f;
-            xi[k] = ok ? xi[k] : 0.f;
+            xr[k] = ok ? xr[k] : (FOLD ? 128.f : 0.f);
+            xi[k] = ok ? xi[k] : (FOLD ? 128.f : 0.f);
         }
     }
 
@@ -411,8 +411,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
     for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = halo.d[j] = 0.f;
 
     if constexpr (RAGGED) {
-        // bounds-checked build (final short chunk only): one row at a time
-        if ((ge & rpc_mask) != 0 && re < a.n_rows) {
+        // bounds-checked build (stream end only): one row at a time
+        if constexpr (fold_unpack<TIN, COND, true>()) {
+#pragma unroll
+            for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = 128.f;  // 0.0f in the folded domain
+        }
+        if ((ge & rpc_mask) != 0 && re < a.rows_readable) {
             float unused[4];
             process_row<TIN, TOUT, COND, true>(load(re), a, halo, lane_valid(re), unused);
         }
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
         // a sample past the chunk end: 0.0f, which is 128 where the unpack bias is folded
         constexpr float kPastEnd = fold_unpack<TIN, COND, false>() ? 128.f : 0.f;
         const bool need_next = (ge & rpc_mask) != 0u;             // segment ends inside a chunk
-        const bool next_in_buffer = need_next && re < a.n_rows;   // ... and the next row is ours to read
+        const bool next_in_buffer = need_next && re < a.rows_readable;  // ... and the next row is ours to read
         const bool next_is_halo = need_next && !next_in_buffer && a.halo != nullptr;
         // The row after the segment is asked for first (it is needed first), from
         // wherever it lives: this buffer, the next shard's first DEMOD_HALO_BYTES

@@ -132,6 +132,11 @@ class Demodulator:
     def head_outputs(self) -> int:
         return self._lib.demod_get_head_outputs(self._ctx)
 
+    def set_seamless(self, on: bool = True) -> None:
+        """Filter the stream as one chunk (look-ahead continues across chunk
+        boundaries); chunk_offset then counts from the start of the stream."""
+        self._check(self._lib.demod_set_seamless(self._ctx, 1 if on else 0), "demod_set_seamless")
+
     def set_segment_rows(self, rows: int) -> None:
         self._check(self._lib.demod_set_segment_rows(self._ctx, rows), "demod_set_segment_rows")
 

@@ -157,6 +157,15 @@ int demod_get_head_outputs(const demod_ctx *ctx);
 int demod_design_query(const demod_params *p, int which, float *rows6, int max_rows, float *taps,
                        int max_taps, float *bias_im, int *n_taps, int *head_outputs);
 
+/* Seamless mode (not reference behaviour; off by default): the whole stream is
+ * filtered as ONE chunk, so the look-ahead stencils run across what would be
+ * chunk boundaries instead of restarting with zero padding every buf_size bytes
+ * (no edge outputs inside the stream; the result equals the reference run with
+ * a chunk as long as the stream).  span.chunk_offset is then the buffer's
+ * offset from the START OF THE STREAM (0 or any multiple of 1024) and every
+ * buffer but the last needs span.halo. */
+int demod_set_seamless(demod_ctx *ctx, int on);
+
 /* Tuning knob: rows (1 KiB of input each) a wavefront streams through before
  * it needs a fresh look-ahead; power of two, 0 = automatic. */
 int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows);

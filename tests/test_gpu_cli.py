@@ -84,3 +84,18 @@ def test_reference_host_on_this_backend(manifest, golden):
         assert got.size == want.size
         opt = dm.Options(**c["flags"])
         assert compare(got, want, dm.design(opt)["taps"], key == "multimon").ok, key
+
+
+def test_cli_seamless_env(manifest, golden):
+    """DEMOD_SEAMLESS=1: the backend adapter holds every hand-off back by one so
+    that it can pass the look-ahead; result = the reference with one long chunk."""
+    data = golden(manifest["fm_like"]["input"])
+    opt = dm.Options(sample_rate=96000.0, lowpass_out=6500.0, lowpass_in=12500.0, buf_size=16384)
+    env = dict(os.environ, DEMOD_SEAMLESS="1")
+    r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-S96000", "-l6500", "-L12500", "-b", "-4"],
+                       input=data.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    got = np.frombuffer(r.stdout, dtype=np.float32)
+    want = oracle.restatement().process(oracle.Flags(**{**opt.__dict__, "buf_size": data.size}), data)
+    assert got.size == want.size
+    assert compare(got, want, dm.design(opt)["taps"], True).ok

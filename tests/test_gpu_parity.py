@@ -284,3 +284,42 @@ def test_random_option_sets_and_lengths(orc):
         assert rep.ok, f"{opt} n_bytes={n_bytes}: {rep}"
         n_cases += 1
     assert n_cases >= 30
+
+
+@pytest.mark.parametrize("flags", [C2, C3, dict(lowpass_in=12500.0, lowpass_out=6500.0, out_degree=7, in_degree=6)],
+                         ids=["C2", "C3", "d7D6"])
+def test_seamless_mode_equals_one_long_chunk(orc, flags):
+    """demod_set_seamless: the look-ahead runs across chunk boundaries; the result
+    is what the reference computes when its chunk is as long as the stream.
+    Also sharded (three buffers with halos) and through the host path."""
+    import torch
+    B = 16384
+    for n_bytes in (9 * B, 5 * B + 3 * 1024, 4 * B + 1500):
+        data = oracle.synth_bytes(2024, 0, n_bytes)
+        opt = dm.Options(buf_size=B, **flags)
+        ref_flags = oracle.Flags(**{**opt.__dict__, "buf_size": n_bytes})
+        want = orc.process(ref_flags, data)
+        taps = dm.design(opt)["taps"]
+        with dm.Demodulator(opt) as d:
+            d.set_seamless(True)
+            iq = torch.from_numpy(data).cuda()
+            whole = d.process(iq).cpu().numpy()
+            assert compare(whole, want, taps, inexact_path(opt.lowpass_in, opt.mode)).ok
+            cuts = [0, 2 * B + 1024, 3 * B + 5 * 1024, n_bytes]
+            parts = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                last = b == n_bytes
+                halo = None if last else torch.cat([iq[b:b + dm.HALO_BYTES],
+                                                    torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device="cuda")])[:dm.HALO_BYTES]
+                parts.append(d.process(iq[a:b].clone(), chunk_offset=a, halo=halo, end_of_stream=last))
+            torch.cuda.synchronize()
+            got = torch.cat(parts).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+            host = d.process_host(data)
+            assert np.array_equal(host.view(np.uint32), whole.view(np.uint32))
+            # and it differs from the chunked result only near chunk boundaries
+            d.set_seamless(False)
+            chunked = d.process(iq).cpu().numpy()
+            diff = np.nonzero(chunked != whole)[0]
+            Ld = B // 4
+            assert diff.size > 0 and np.all(((diff % Ld) < 32) | ((diff % Ld) >= Ld - 8))
