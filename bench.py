@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X-native FM-demodulation hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c2|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c2|c3|c4|c5]
 
 A "step" is one pass of the hot path (one call of demod_process_device through
 the C ABI: the fused streaming kernel + the chunk-head kernel) over one shard of
@@ -12,6 +12,8 @@ Workloads (BASELINE.json / SURVEY.md section 8d):
     target  2^32 samples per GPU, -L 12500 -l 6500   (north_star target; default)
     c3      2^30 samples per GPU, -L 12500 -l 6500   (configs[2])
     c2      2^30 samples per GPU, no -L, default -l  (configs[1])
+    c4      2^31 samples per GPU of one sharded stream (configs[3]: 2^34 at 8 GPUs)
+    c5      32 channels x 2^24 samples per GPU, batched (configs[4]: 256 channels at 8 GPUs)
 
 For N > 1 the driver launches one process per GPU with torch.distributed.run;
 the global stream is cut into N contiguous shards.  By default the cut points
@@ -50,6 +52,14 @@ WORKLOADS = {
                desc="2^30-sample synthetic uint8 IQ per GPU, -L 12500 -l 6500"),
     "c2": dict(log2_samples=30, flags=dict(), seed=0xD3300D02,
                desc="2^30-sample synthetic uint8 IQ per GPU, no -L, default -l"),
+    # configs[3]: 2^34 samples over 8 GPUs = 2^31 per GPU (weak scaling keeps that share at every N)
+    "c4": dict(log2_samples=31, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D04,
+               desc="2^31-sample shard per GPU of one stream (2^34 samples at 8 GPUs), -L 12500 -l 6500"),
+    # configs[4]: 256 channels x 2^24 samples over 8 GPUs = 32 channels per GPU.  Channels are
+    # independent streams of whole chunks, so a GPU's channels are laid back to back and go
+    # through ONE launch (chunks never interact: tests/test_gpu_parity.py::test_batched_channels)
+    "c5": dict(log2_samples=29, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D05,
+               desc="32 channels x 2^24 samples per GPU (256 channels at 8 GPUs), batched in one launch, -L 12500 -l 6500"),
 }
 PHASE_BYTES = 96 * 1024  # unaligned cut: shards start this far into a chunk
 

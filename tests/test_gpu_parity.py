@@ -323,3 +323,22 @@ def test_seamless_mode_equals_one_long_chunk(orc, flags):
             diff = np.nonzero(chunked != whole)[0]
             Ld = B // 4
             assert diff.size > 0 and np.all(((diff % Ld) < 32) | ((diff % Ld) >= Ld - 8))
+
+
+def test_batched_channels(orc):
+    """BASELINE config 5 in small: independent channels, each a whole number of
+    chunks, laid back to back and demodulated in ONE launch give bit for bit
+    what each channel gives alone (chunks never interact), and match the oracle
+    per channel."""
+    import torch
+    opt = dm.Options(buf_size=16384, **C3)
+    n_ch, per_ch = 12, 8 * 16384
+    chans = [oracle.synth_bytes(0xD3300D05 + c, 0, per_ch) for c in range(n_ch)]
+    fl = oracle.Flags(**opt.__dict__)
+    taps = dm.design(opt)["taps"]
+    with dm.Demodulator(opt) as d:
+        batch = d.process(torch.from_numpy(np.concatenate(chans)).cuda()).cpu().numpy().reshape(n_ch, -1)
+        for c in range(n_ch):
+            alone = d.process(torch.from_numpy(chans[c]).cuda()).cpu().numpy()
+            assert np.array_equal(alone.view(np.uint32), batch[c].view(np.uint32)), c
+            assert compare(batch[c], orc.process(fl, chans[c]), taps, True).ok, c
