@@ -114,9 +114,9 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
     p = fmaf(p, s, -3.332985938e-01f);
     p = fmaf(p, s, 9.999993443e-01f);
 #endif
-    float r = p * q;                                               // atan(lo / hi) in [0, pi/4]
-    // |y| > |x|:  pi/2 - r  ==  |r - pi/2|
-    r = r - __uint_as_float(swap & 0x3FC90FDBu);
+    // r = atan(lo / hi) in [0, pi/4];  |y| > |x|:  pi/2 - r  ==  |r - pi/2|, the
+    // subtraction riding on the polynomial's last multiply
+    float r = fmaf(p, q, __uint_as_float(swap & 0xBFC90FDBu));
     // x negative (sign bit, so -0 counts):  pi - r'  ==  |r' - pi|
     const uint32_t xneg = (uint32_t) ((int32_t) xb >> 31);
     r = fabsf(r) - __uint_as_float(xneg & 0x40490FDBu);
