@@ -25,7 +25,7 @@ EXPORTS = (
     "demod_free_pinned", "demod_alloc_device", "demod_free_device", "demod_copy_to_device",
     "demod_copy_to_host", "demod_synchronize", "demod_get_sos", "demod_get_taps",
     "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_segment_rows", "demod_synth_fill",
-    "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms",
+    "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
     "demod_enable_timing",
 )
 
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
         "demod_selftest_atan2": (i32, [vp, vp, vp, vp, u32]),
         "demod_selftest_lane_shift": (i32, [vp, vp, C.c_float, vp]),
         "demod_kernel_ms": (C.c_double, [vp, C.POINTER(i32)]),
+        "demod_last_call_launches": (i32, [vp]),
         "demod_enable_timing": (None, [vp, i32]),
     }
     for name in EXPORTS:

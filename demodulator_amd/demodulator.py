@@ -205,8 +205,13 @@ class Demodulator:
     def enable_timing(self, on: bool = True) -> None:
         self._lib.demod_enable_timing(self._ctx, 1 if on else 0)
 
+    @property
+    def last_call_launches(self) -> int:
+        """Dispatches of the fused kernel in the most recent process call."""
+        return self._lib.demod_last_call_launches(self._ctx)
+
     def kernel_ms(self):
-        """(average fused-kernel milliseconds, launches) since the last call."""
+        """(average fused-kernel milliseconds per process call, calls) since the last call."""
         n = C.c_int(0)
         ms = self._lib.demod_kernel_ms(self._ctx, C.byref(n))
         return float(ms), int(n.value)

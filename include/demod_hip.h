@@ -183,11 +183,15 @@ int demod_selftest_atan2(demod_ctx *ctx, const float *h_y, const float *h_x, flo
                          uint32_t n);
 int demod_selftest_lane_shift(demod_ctx *ctx, const float *h_in64, float halo, float *h_out64);
 
-/* Average duration in milliseconds of the fused kernel over the process calls
- * issued since the previous call to this function, measured with HIP events
- * on the stream the kernel was launched on.  Enables event recording on first
- * use; returns < 0 if nothing was recorded. */
-double demod_kernel_ms(demod_ctx *ctx, int *launches);
+/* Average time in milliseconds the fused kernel took per process call, over the
+ * calls issued since the previous call to this function, measured with HIP
+ * events on the stream the kernel was launched on (a call that covers more than
+ * 2 GiB of input dispatches the kernel once per 2 GiB piece, back to back; the
+ * events bracket all of them).  *calls = number of calls averaged.  Enables
+ * event recording on first use; returns < 0 if nothing was recorded.
+ * demod_last_call_launches: dispatches of the fused kernel in the most recent call. */
+double demod_kernel_ms(demod_ctx *ctx, int *calls);
+int demod_last_call_launches(const demod_ctx *ctx);
 void demod_enable_timing(demod_ctx *ctx, int on);
 
 #ifdef __cplusplus
