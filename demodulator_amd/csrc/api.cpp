@@ -44,6 +44,7 @@ struct demod_ctx {
     bool heads_inline = false;
     bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
     uint32_t seg_rows = 0;  // 0 = automatic
+    uint32_t piece_rows = kPieceRows;  // rows per demod_rows dispatch
     int last_row_launches = 0;  // demod_rows dispatches issued by the most recent process call
 
     // kernel timing (HIP events on the launch stream)
@@ -207,6 +208,17 @@ int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows) {
 int demod_set_seamless(demod_ctx *ctx, int on) {
     if (!ctx) return DEMOD_E_INVAL;
     ctx->seamless = on != 0;
+    return DEMOD_OK;
+}
+
+int demod_set_piece_rows(demod_ctx *ctx, uint32_t rows) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (rows == 0) rows = kPieceRows;
+    if ((rows & (rows - 1)) || rows < max_segment_rows()) {
+        ctx->fail(DEMOD_E_INVAL, "piece rows must be a power of two, at least one segment");
+        return DEMOD_E_INVAL;
+    }
+    ctx->piece_rows = rows;
     return DEMOD_OK;
 }
 
@@ -452,7 +464,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             uint32_t p0 = 0;
             while (p0 < split) {
                 uint32_t p1 = (uint32_t) std::min<uint64_t>(
-                    split, ((uint64_t) (phase + p0) / kPieceRows + 1) * kPieceRows - phase);
+                    split, ((uint64_t) (phase + p0) / ctx->piece_rows + 1) * ctx->piece_rows - phase);
                 RowLaunch a = r;
                 a.in = d_in + (uint64_t) p0 * kRowBytes;
                 a.out = d_out + (uint64_t) p0 * kRowOutputs;

@@ -137,6 +137,9 @@ class Demodulator:
         boundaries); chunk_offset then counts from the start of the stream."""
         self._check(self._lib.demod_set_seamless(self._ctx, 1 if on else 0), "demod_set_seamless")
 
+    def set_piece_rows(self, rows: int) -> None:
+        self._check(self._lib.demod_set_piece_rows(self._ctx, rows), "demod_set_piece_rows")
+
     def set_segment_rows(self, rows: int) -> None:
         self._check(self._lib.demod_set_segment_rows(self._ctx, rows), "demod_set_segment_rows")
 

@@ -170,6 +170,11 @@ int demod_set_seamless(demod_ctx *ctx, int on);
  * it needs a fresh look-ahead; power of two, 0 = automatic. */
 int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows);
 
+/* Tuning knob: rows per dispatch of the fused kernel (a call covering more is
+ * cut into that many back-to-back dispatches); power of two, 0 = default
+ * (2^21 rows = 2 GiB of input). */
+int demod_set_piece_rows(demod_ctx *ctx, uint32_t rows);
+
 /* Counter-based synthetic IQ bytes written straight into device memory
  * (benchmark input): byte i of stream `seed` is byte
  * (i & 7) of splitmix64 word (i >> 3).  first_byte and n_bytes multiples of 16. */

@@ -342,3 +342,32 @@ def test_batched_channels(orc):
             alone = d.process(torch.from_numpy(chans[c]).cuda()).cpu().numpy()
             assert np.array_equal(alone.view(np.uint32), batch[c].view(np.uint32)), c
             assert compare(batch[c], orc.process(fl, chans[c]), taps, True).ok, c
+
+
+@pytest.mark.parametrize("flags", [C2, C3], ids=["C2", "C3"])
+def test_launch_pieces_do_not_change_results(flags):
+    """A call is cut into back-to-back dispatches of the fused kernel (2 GiB of
+    input each by default); forcing tiny pieces on a small stream, with and
+    without a chunk offset, a halo and a ragged tail, changes no bit."""
+    import torch
+    opt = dm.Options(buf_size=65536, **flags)
+    data = oracle.synth_bytes(4242, 0, 5 * 65536 + 24 * 1024 + 700)
+    iq = torch.from_numpy(data).cuda()
+    with dm.Demodulator(opt) as d:
+        ref_whole = d.process(iq).cpu().numpy()
+        assert d.last_call_launches <= 2
+        n1 = 3 * 65536 + 9 * 1024
+        halo = iq[n1:n1 + dm.HALO_BYTES].clone()
+        ref_a = d.process(iq[:n1].clone(), halo=halo, end_of_stream=False).cpu().numpy()
+        ref_b = d.process(iq[n1:].clone(), chunk_offset=n1 % 65536).cpu().numpy()
+        for rows in (8, 16, 64):
+            d.set_piece_rows(rows)
+            got = d.process(iq).cpu().numpy()
+            assert d.last_call_launches > 4
+            assert np.array_equal(got.view(np.uint32), ref_whole.view(np.uint32)), rows
+            a = d.process(iq[:n1].clone(), halo=halo, end_of_stream=False).cpu().numpy()
+            b = d.process(iq[n1:].clone(), chunk_offset=n1 % 65536).cpu().numpy()
+            assert np.array_equal(a.view(np.uint32), ref_a.view(np.uint32)), rows
+            assert np.array_equal(b.view(np.uint32), ref_b.view(np.uint32)), rows
+        d.set_piece_rows(0)
+        assert np.array_equal(np.concatenate([ref_a, ref_b]).view(np.uint32), ref_whole.view(np.uint32))
