@@ -371,3 +371,35 @@ def test_launch_pieces_do_not_change_results(flags):
             assert np.array_equal(b.view(np.uint32), ref_b.view(np.uint32)), rows
         d.set_piece_rows(0)
         assert np.array_equal(np.concatenate([ref_a, ref_b]).view(np.uint32), ref_whole.view(np.uint32))
+
+
+def test_argument_errors_are_reported_not_computed():
+    """Misuse of the C ABI returns DEMOD_E_INVAL with a message (no partial work)."""
+    import torch
+    with dm.Demodulator(dm.Options(buf_size=16384)) as d:
+        iq = torch.zeros(4 * 16384 + 64, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(16384 + 16, dtype=torch.float32, device="cuda")
+        with pytest.raises(dm.DemodError, match="16-byte aligned"):
+            d.process_ptr(iq.data_ptr() + 4, 1024, out.data_ptr())                   # misaligned input
+        with pytest.raises(dm.DemodError, match="multiple of 4"):
+            d.process_ptr(iq.data_ptr(), 1022, out.data_ptr())
+        with pytest.raises(dm.DemodError, match="halo is required"):
+            d.process_ptr(iq.data_ptr(), 16384 + 1024, out.data_ptr(), end_of_stream=False)  # ends inside a chunk
+        with pytest.raises(dm.DemodError, match="multiples of 1024"):
+            d.process_ptr(iq.data_ptr(), 16384 + 100, out.data_ptr(), end_of_stream=False, halo_ptr=iq.data_ptr())
+        with pytest.raises(dm.DemodError, match="chunk_offset"):
+            d.process_ptr(iq.data_ptr(), 1024, out.data_ptr(), chunk_offset=16384)     # offset must be < chunk
+        with pytest.raises(dm.DemodError, match="chunk_offset"):
+            d.process_ptr(iq.data_ptr(), 1024, out.data_ptr(), chunk_offset=100)
+        with pytest.raises(dm.DemodError):
+            d.set_segment_rows(3)
+        with pytest.raises(dm.DemodError):
+            d.set_piece_rows(4)
+        d.process_ptr(iq.data_ptr(), 0, out.data_ptr())                                # empty: fine, nothing launched
+    with dm.Demodulator(dm.Options(buf_size=64)) as d:
+        iq = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(256, dtype=torch.float32, device="cuda")
+        with pytest.raises(dm.DemodError, match="whole chunks"):
+            d.process_ptr(iq.data_ptr(), 100, out.data_ptr(), end_of_stream=False)
+        with pytest.raises(dm.DemodError, match="chunk_offset must be 0"):
+            d.process_ptr(iq.data_ptr(), 128, out.data_ptr(), chunk_offset=1024)
