@@ -125,7 +125,13 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
         if me.needs_halo or me.sends_halo:
             # RCCL send/recv: my first 64 bytes go to the rank on my left, the
             # first 64 bytes of the rank on my right come to me
-            exchange_halo(me, right, iq, halo)
+            if dist.get_backend() == "nccl":
+                exchange_halo(me, right, iq, halo)
+            else:  # rehearsal backend: through host memory
+                mine = iq[: dm.HALO_BYTES].cpu()
+                theirs = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8)
+                exchange_halo(me, right, mine, theirs)
+                halo.copy_(theirs)
         d.process(iq, out, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
                   end_of_stream=me.end_of_stream)
 
@@ -190,16 +196,22 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the demodulation path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    # DEMOD_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the 64-byte halos travel through host memory); never for reported numbers
+    backend = os.environ.get("DEMOD_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", torch.cuda.current_device()))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
                      args.segment_rows, args.prewarm_ms)
     dt = r["dt"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -226,7 +238,8 @@ def main() -> None:
             "sharding": ("1 GPU" if world == 1 else
                          f"{world} contiguous shards, " +
                          ("chunk-aligned cuts, no exchange" if not r["phase"] else
-                          f"cuts {r['phase']} B into a chunk, 64-byte look-ahead via RCCL send/recv per step")),
+                          f"cuts {r['phase']} B into a chunk, 64-byte look-ahead via "
+                          f"{'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} send/recv per step")),
         },
     }
     if rank == 0:

@@ -455,16 +455,17 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         if (split) {
             // The full rows go out in pieces of at most kPieceRows (2 GiB of input):
             // on MI355X one 8 GiB launch runs ~4 % slower per sample than four 2 GiB
-            // launches back to back (tools/split_probe.py).  Pieces start on
-            // multiples of kPieceRows counted from the chunk origin, hence on
-            // segment boundaries; a piece looks ahead into the next piece's first
-            // row through rows_readable.
+            // launches back to back (tools/split_probe.py).  Pieces are piece_rows
+            // long and start on segment boundaries (counted from the chunk origin);
+            // a piece looks ahead into the next piece's first row through
+            // rows_readable.
             const uint32_t readable = ragged ? split + 1 : split;
             const uint32_t phase = r.phase_rows;
             uint32_t p0 = 0;
             while (p0 < split) {
+                const uint32_t seg_rows = 1u << seg_log2;
                 uint32_t p1 = (uint32_t) std::min<uint64_t>(
-                    split, ((uint64_t) (phase + p0) / ctx->piece_rows + 1) * ctx->piece_rows - phase);
+                    split, (uint64_t) p0 + ctx->piece_rows - ((phase + p0) & (seg_rows - 1u)));
                 RowLaunch a = r;
                 a.in = d_in + (uint64_t) p0 * kRowBytes;
                 a.out = d_out + (uint64_t) p0 * kRowOutputs;
