@@ -83,6 +83,8 @@ typedef struct demod_span {
     uint32_t reserved;
 } demod_span;
 
+/* A context belongs to one HIP device and is NOT thread-safe: use it from one
+ * host thread at a time (several contexts may be used concurrently). */
 typedef struct demod_ctx demod_ctx;
 
 /* Fill p with the reference's defaults. */
