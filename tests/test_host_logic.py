@@ -144,3 +144,19 @@ def test_cli_fails_loudly_without_gpu():
     assert r.returncode != 0 and b"no ROCm-capable device" in r.stderr   # no silent CPU path
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode != 0                       # argc < 3, src/main.c:122-124
+
+
+def test_hand_counted_waits_cover_every_asm_load():
+    """Static replay of the generated gfx950 assembly of every demod_rows
+    instantiation: no instruction touches a register of an inline-asm row load
+    before the hand-counted s_waitcnt that covers it (tools/check_asm_waits.py)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_waits.py")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
+    assert b" 0 violations" in r.stdout

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Static check of the hand-counted waits in demod_rows (kernels.hip).
+
+The streaming kernel issues its row loads from inline asm, invisible to hipcc's
+own s_waitcnt bookkeeping, and waits for them with hand-counted `s_waitcnt
+vmcnt(N)` statements.  The hazard is the compiler
+reading or overwriting a destination register of such a load before the wait
+that covers it (it believes the value is there at ;;#ASMEND).  This script
+compiles kernels.hip to gfx950 assembly and replays every demod_rows function:
+vector-memory operations retire in issue order, so after `s_waitcnt vmcnt(N)`
+everything but the N youngest operations has landed; any instruction that
+touches a register of a load that has not landed yet is reported.
+
+    python tools/check_asm_waits.py            # exit code 1 on a violation
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "demodulator_amd", "csrc", "kernels.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm",
+         "-amdgpu-sched-strategy=max-ilp", "-Wno-pass-failed", f"-I{ROOT}/include",
+         f"-I{ROOT}/demodulator_amd/csrc", "-S", "--cuda-device-only"]
+
+REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs(text: str) -> set[int]:
+    out: set[int] = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def check_function(name: str, lines: list[str]) -> list[str]:
+    problems = []
+    queue: list[tuple[str, set[int]]] = []   # in-flight vector-memory ops, oldest first: (kind, dest regs)
+    in_asm = False
+    n_asm_loads = n_waits = 0
+    for ln, raw in lines:
+        line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        op = line.split()[0]
+        operands = line[len(op):]
+        if op.startswith("s_waitcnt"):
+            m = re.search(r"vmcnt\((\d+)\)", line)
+            if m:
+                n = int(m.group(1))
+                if in_asm:
+                    n_waits += 1
+                while len(queue) > n:
+                    queue.pop(0)
+            continue
+        pending = set().union(*(r for k, r in queue if k == "asmload")) if queue else set()
+        if op.startswith(("global_load", "buffer_load", "flat_load")):
+            parts = operands.split(",")
+            dest = regs(parts[0])
+            touched = regs(",".join(parts[1:]))
+            if touched & pending or dest & pending:
+                problems.append(f"{name}:{ln}: `{line}` touches registers of a load still in flight: "
+                                f"{sorted((touched | dest) & pending)}")
+            queue.append(("asmload" if in_asm else "load", dest))
+            n_asm_loads += in_asm
+            continue
+        if op.startswith(("global_store", "buffer_store", "flat_store")):
+            touched = regs(operands)
+            if touched & pending:
+                problems.append(f"{name}:{ln}: `{line}` reads registers of a load still in flight: "
+                                f"{sorted(touched & pending)}")
+            queue.append(("store", set()))
+            continue
+        if op.startswith(("s_endpgm",)):
+            queue.clear()   # a path ends; the next basic block listed starts from its own predecessors
+            continue
+        if op.startswith(("s_", "ds_")) and not op.startswith("ds_"):
+            continue
+        touched = regs(operands)
+        if touched & pending:
+            problems.append(f"{name}:{ln}: `{line}` touches registers of a load still in flight: "
+                            f"{sorted(touched & pending)}")
+    return problems, n_asm_loads, n_waits
+
+
+def main() -> int:
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "kernels.s")
+        subprocess.run([HIPCC, *FLAGS, SRC, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read().split("\n")
+    funcs: dict[str, list] = {}
+    cur = None
+    for i, l in enumerate(text, 1):
+        m = re.match(r"^(_ZN5demod\S*demod_rows\S*):", l)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+            continue
+        if cur is not None:
+            if l.startswith(".Lfunc_end"):
+                cur = None
+                continue
+            funcs[cur].append((i, l))
+    total_loads = total_waits = 0
+    problems = []
+    for name, lines in funcs.items():
+        p, nl, nw = check_function(name, lines)
+        problems += p
+        total_loads += nl
+        total_waits += nw
+    print(f"checked {len(funcs)} demod_rows instantiations: {total_loads} asm loads, {total_waits} hand-counted waits, "
+          f"{len(problems)} violations")
+    for p in problems[:20]:
+        print("  ", p)
+    return 1 if problems or not funcs or total_loads == 0 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
