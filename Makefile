@@ -4,6 +4,7 @@
 #   make backend  demodulator_amd/libdemod_backend.so  (processMatrix/allocateBuffer adapter)
 #   make cli      demodulator_amd/demod                (C host, reference CLI contract)
 #   make oracle   oracle/libdemod_oracle.so (+ oracle/_ref when /root/reference exists)
+#   make microbench  tools/microbench/{valu_rate,stream_copy}
 #
 # Everything is built in-tree so the binaries travel to the GPU box with the
 # source snapshot.
@@ -43,8 +44,13 @@ $(PKG)/demod: $(SRC)/main.c include/demod_backend.h include/demod_hip.h $(PKG)/l
 oracle:
 	$(MAKE) -C oracle
 
+# instruction-rate and streaming-pattern microbenchmarks behind DESIGN.md section 4.1 (run on the GPU box)
+microbench: tools/microbench/valu_rate tools/microbench/stream_copy
+tools/microbench/%: tools/microbench/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
 clean:
 	rm -f $(PKG)/libdemod_hip.so $(PKG)/libdemod_backend.so $(PKG)/demod
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib backend cli oracle clean
+.PHONY: all lib backend cli oracle microbench clean
