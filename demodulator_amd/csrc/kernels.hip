@@ -132,6 +132,16 @@ __device__ __forceinline__ float discriminate(float a, float b, float c, float d
     return fast_atan2(zj, zr);
 }
 
+// The same with the reference's rounding (two products, one sum, src/matrix.c:170-171),
+// for the literal-replay kernels: their inputs are bit-identical to the reference's, so
+// zr and zj are too, and no +pi / -pi ambiguity can arise where the chunk-head weights
+// make it hard to recognise.
+__device__ __forceinline__ float discriminate_literal(float a, float b, float c, float d) {
+    const float zr = a * c + b * d;
+    const float zj = -a * d + b * c;
+    return fast_atan2(zj, zr);
+}
+
 // Four bytes -> (byte + 1) & 255 each, all four at once (SWAR): adding 1 to the
 // low 7 bits of every byte cannot carry into the next byte; the carry into bit 7
 // is folded in with an xor.  (byte + 1) & 255 == (int8_t)(byte - 127) + 128.
@@ -689,11 +699,11 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
         }
 #pragma unroll
         for (int n = 0; n < W; ++n)
-            d[n] = n < Ld ? discriminate(zr[2 * n], zi[2 * n], zr[2 * n + 1], zi[2 * n + 1]) : 0.f;
+            d[n] = n < Ld ? discriminate_literal(zr[2 * n], zi[2 * n], zr[2 * n + 1], zi[2 * n + 1]) : 0.f;
     } else {
 #pragma unroll
         for (int n = 0; n < W; ++n)
-            d[n] = n < Ld ? discriminate(sample(2 * n, 0), sample(2 * n, 1), sample(2 * n + 1, 0),
+            d[n] = n < Ld ? discriminate_literal(sample(2 * n, 0), sample(2 * n, 1), sample(2 * n + 1, 0),
                                          sample(2 * n + 1, 1))
                           : 0.f;
     }
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
             y2 = F + 2 * B;
         }
         for (uint32_t n = 0; n < Ld; ++n)
-            dem[n] = discriminate(src[4 * n], src[4 * n + 1], src[4 * n + 2], src[4 * n + 3]);
+            dem[n] = discriminate_literal(src[4 * n], src[4 * n + 1], src[4 * n + 2], src[4 * n + 3]);
         for (uint32_t i = 0; i < Ld; ++i) {
             for (int m = 0; m < So; ++m) {
                 const uint32_t n = i + So + m;
