@@ -6,10 +6,11 @@
 //              look-ahead stencil] -> conjugate-multiply discriminator + atan2
 //              -> real look-ahead stencil -> float32.  One wavefront streams a
 //              segment of 1 KiB rows from its end to its start, so the
-//              look-ahead values a row needs from the row after it are already
-//              in scalar registers; inside a row they come from the next lane
-//              by a DPP wave shift.  No LDS, no barriers, 16-byte loads and
-//              stores, 4 B of HBM traffic per IQ sample.
+//              look-ahead values a row needs from the row after it have been
+//              computed already; they and the next lane's values inside a row
+//              travel through a per-wavefront exchange line in LDS (no
+//              barriers).  16-byte loads and stores, 4 B of HBM traffic per IQ
+//              sample.
 // demod_heads  literal replay of the reference's sectioned recurrences for the
 //              first few outputs of every chunk (partial sections, overflow
 //              pollution).
@@ -39,14 +40,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DEMOD_LOAD_POLICY " nt"   // cache policy suffix of the streaming loads: every byte is read once
 #endif
 #ifndef DEMOD_WAVES_PER_BLOCK
-#define DEMOD_WAVES_PER_BLOCK 4
+#define DEMOD_WAVES_PER_BLOCK 8
 #endif
 constexpr int kWavesPerBlock = DEMOD_WAVES_PER_BLOCK;  // independent wavefronts per workgroup of demod_rows
 #ifndef DEMOD_EXACT_WAITS
 #define DEMOD_EXACT_WAITS 1
 #endif
 #ifndef DEMOD_ROWS_PER_WAVE
-#define DEMOD_ROWS_PER_WAVE 8
+#define DEMOD_ROWS_PER_WAVE 4
 #endif
 constexpr int kGroup = DEMOD_ROWS_PER_WAVE;  // rows (1 KiB each) one wavefront owns and keeps in flight
 
@@ -87,7 +88,8 @@ __device__ __forceinline__ uint32_t bit_select(uint32_t a, uint32_t b, uint32_t 
 // (8 coefficients, |error| < 7e-8 before rounding), one v_rcp_f32.  The octant
 // logic is written with sign-bit masks instead of compares and selects so that
 // everything except the reciprocal is a full-rate VALU operation.
-__device__ __forceinline__ float fast_atan2(float y, float x) {
+constexpr float kAtanLead = -4.054567311e-03f;  // leading coefficient of the polynomial below
+__device__ __forceinline__ float fast_atan2(float y, float x, float lead = kAtanLead) {
     const uint32_t xb = __float_as_uint(x), yb = __float_as_uint(y);
     const float t = fabsf(x) - fabsf(y);
     const uint32_t swap = (uint32_t) (__float_as_int(t) >> 31);  // all ones when |y| > |x|
@@ -96,24 +98,16 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
     // v_mul_legacy_f32: 0 * anything = 0, so atan2(0, 0) (lo = 0, 1/hi = inf) gives q = 0
     const float q = fmul_legacy(lo, __builtin_amdgcn_rcpf(hi));
     const float s = q * q;
-#ifdef DEMOD_ATAN_7COEF
-    float p = 6.811792962e-03f;
-    p = fmaf(p, s, -3.360421956e-02f);
-    p = fmaf(p, s, 7.962366939e-02f);
-    p = fmaf(p, s, -1.323334277e-01f);
-    p = fmaf(p, s, 1.980781555e-01f);
-    p = fmaf(p, s, -3.331736922e-01f);
-    p = fmaf(p, s, 9.999961257e-01f);
-#else
-    float p = -4.054567311e-03f;
-    p = fmaf(p, s, 2.186295763e-02f);
+    // `lead` is kAtanLead; the streaming kernel hands it in from a register it keeps
+    // for the whole segment (gfx9 encodings take one literal or scalar per instruction,
+    // so "c7 * s + c6" would otherwise start with a v_mov of c7 for every output)
+    float p = fmaf(lead, s, 2.186295763e-02f);
     p = fmaf(p, s, -5.591232702e-02f);
     p = fmaf(p, s, 9.642197192e-02f);
     p = fmaf(p, s, -1.390862912e-01f);
     p = fmaf(p, s, 1.994656622e-01f);
     p = fmaf(p, s, -3.332985938e-01f);
     p = fmaf(p, s, 9.999993443e-01f);
-#endif
     // r = atan(lo / hi) in [0, pi/4];  |y| > |x|:  pi/2 - r  ==  |r - pi/2|, the
     // subtraction riding on the polynomial's last multiply
     float r = fmaf(p, q, __uint_as_float(swap & 0xBFC90FDBu));
@@ -126,10 +120,10 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
 
 // Quadrature discriminator of one pair of complex samples z0 = a + ib,
 // z1 = c + id: arg(z0 * conj(z1)), src/matrix.c:170-173.
-__device__ __forceinline__ float discriminate(float a, float b, float c, float d) {
+__device__ __forceinline__ float discriminate(float a, float b, float c, float d, float lead = kAtanLead) {
     const float zr = fmaf(b, d, a * c);
     const float zj = fmaf(b, c, (-a) * d);
-    return fast_atan2(zj, zr);
+    return fast_atan2(zj, zr, lead);
 }
 
 // The same with the reference's rounding (two products, one sum, src/matrix.c:170-171),
@@ -205,6 +199,76 @@ struct Halo {
     float d[kMaxTaps - 1];   // its first discriminator outputs
 };
 
+// How the lanes of a row get the values that follow their own 16 bytes: each lane
+// needs the first few samples (and discriminator outputs) of the lane after it,
+// lane 63 those of lane 0 of the row that follows.  Rows are processed from the
+// end of a segment to its start, so that row has always been seen already.
+//
+// (1) Registers: v_mov_b32 with a DPP wave shift inside the row, the following
+//     row's lane-0 values in scalar registers (v_readfirstlane).  Three VALU
+//     operations per value and row; used by the bounds-checked build.
+struct RegisterExchange {
+    Halo &halo;
+    template <int N>
+    __device__ __forceinline__ void next_x(float *xr, float *xi) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            xr[8 + j] = from_next_lane(xr[j], halo.xr[j]);
+            xi[8 + j] = from_next_lane(xi[j], halo.xi[j]);
+            halo.xr[j] = wave_first(xr[j]);
+            halo.xi[j] = wave_first(xi[j]);
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void next_d(float *d) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            d[4 + j] = from_next_lane(d[j], halo.d[j]);
+            halo.d[j] = wave_first(d[j]);
+        }
+    }
+};
+
+// (2) LDS: every lane writes its first values to its slot of the row's exchange
+//     line and reads the slot after it; lane 63 reads slot 0 of the line the
+//     following row wrote (two lines per wavefront, used alternately).  The LDS
+//     queue takes these instead of the VALU, which is the unit this kernel is
+//     short of.  One wavefront's LDS operations execute in order, so no barrier
+//     is needed: a line is only ever touched by the wavefront that owns it.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct LdsExchange {
+    lds_float *wr_x;
+    const lds_float *rd_x;
+    lds_float *wr_d;
+    const lds_float *rd_d;
+    template <int N>
+    __device__ __forceinline__ void next_x(float *xr, float *xi) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            f32x2 v;
+            v.x = xr[j];
+            v.y = xi[j];
+            *reinterpret_cast<__attribute__((address_space(3))) f32x2 *>(wr_x + 2 * j) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const f32x2 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(rd_x + 2 * j);
+            xr[8 + j] = v.x;
+            xi[8 + j] = v.y;
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void next_d(float *d) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) wr_d[j] = d[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < N; ++j) d[4 + j] = rd_d[j];
+    }
+};
+
 // T-tap forward stencil  sum_j h[j] * v[j]  (+ c0 folded into the first product)
 template <int T>
 __device__ __forceinline__ float stencil(const float *h, const float *v, float c0) {
@@ -231,11 +295,10 @@ template <int TIN, int COND, bool RAGGED>
 constexpr bool fold_unpack() { return TIN > 0 && COND == kShiftOrigin; }  // every build: results must not depend on which one ran
 
 // One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
-// `valid` = usable bytes of this lane's 16 (16 unless RAGGED).
-// halo: in  = look-ahead from the following row (lane 0 of it),
-//       out = this row's lane-0 values for the row before it.
-template <int TIN, int TOUT, int COND, bool RAGGED>
-__device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, Halo &halo, int valid,
+// `valid` = usable bytes of this lane's 16 (16 unless RAGGED); `ex` supplies the
+// look-ahead values and takes this row's for the row before it; `lead`: see fast_atan2.
+template <int TIN, int TOUT, int COND, bool RAGGED, class EX>
+__device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, EX &ex, int valid, float lead,
                                             float (&y)[4]) {
     constexpr int NX = 8 + (TIN > 0 ? TIN - 1 : 0);
     constexpr int ND = 4 + TOUT - 1;
@@ -258,11 +321,7 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, H
     float d[ND];
     if constexpr (TIN > 0) {
         // complex samples 8.. come from the next lane
-#pragma unroll
-        for (int j = 0; j < TIN - 1; ++j) {
-            xr[8 + j] = from_next_lane(xr[j], halo.xr[j]);
-            xi[8 + j] = from_next_lane(xi[j], halo.xi[j]);
-        }
+        if constexpr (TIN > 1) ex.template next_x<TIN - 1>(xr, xi);
         float zr[8], zi[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -275,30 +334,20 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, H
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = discriminate(zr[2 * j], zi[2 * j], zr[2 * j + 1], zi[2 * j + 1]);
+        for (int j = 0; j < 4; ++j)
+            d[j] = discriminate(zr[2 * j], zi[2 * j], zr[2 * j + 1], zi[2 * j + 1], lead);
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = discriminate(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1]);
+        for (int j = 0; j < 4; ++j)
+            d[j] = discriminate(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1], lead);
     }
     if constexpr (RAGGED) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = 4 * j < valid ? d[j] : 0.f;
     }
-#pragma unroll
-    for (int j = 0; j < TOUT - 1; ++j) d[4 + j] = from_next_lane(d[j], halo.d[j]);
+    if constexpr (TOUT > 1) ex.template next_d<TOUT - 1>(d);
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = stencil0<TOUT>(a.hout, &d[j]);
-
-    // hand this row's lane-0 values to the row before it
-    if constexpr (TIN > 1) {
-#pragma unroll
-        for (int j = 0; j < TIN - 1; ++j) {
-            halo.xr[j] = wave_first(xr[j]);
-            halo.xi[j] = wave_first(xi[j]);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < TOUT - 1; ++j) halo.d[j] = wave_first(d[j]);
 }
 
 // Look-ahead a segment needs from the row after it: only that row's lane-0
@@ -348,7 +397,8 @@ __device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunc
         }
     } else {
         float unused[4];
-        process_row<TIN, TOUT, COND, false>(w, a, halo, 16, unused);
+        RegisterExchange ex{halo};
+        process_row<TIN, TOUT, COND, false>(w, a, ex, 16, kAtanLead, unused);
     }
 }
 
@@ -426,14 +476,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
 #pragma unroll
             for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = 128.f;  // 0.0f in the folded domain
         }
+        RegisterExchange ex{halo};
         if ((ge & rpc_mask) != 0 && re < a.rows_readable) {
             float unused[4];
-            process_row<TIN, TOUT, COND, true>(load(re), a, halo, lane_valid(re), unused);
+            process_row<TIN, TOUT, COND, true>(load(re), a, ex, lane_valid(re), kAtanLead, unused);
         }
         for (uint32_t r = re; r-- > rb;) {
             float y[4];
             const int valid = lane_valid(r);
-            process_row<TIN, TOUT, COND, true>(load(r), a, halo, valid, y);
+            process_row<TIN, TOUT, COND, true>(load(r), a, ex, valid, kAtanLead, y);
             const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
             float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
             if (!head) {
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
             }
         }
     } else {
-        // A wavefront owns at most kGroup rows (4 KiB by default) and asks for all
+        // A wavefront owns at most kGroup rows (4 KiB of input by default) and asks for all
         // of them, plus the row that follows when the segment ends inside a chunk,
         // before it computes anything: short-lived wavefronts over a compact,
         // advancing window of memory are what reaches the HBM streaming rate
@@ -469,17 +520,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
                                               : a.in + (uint64_t) rb * kRowBytes;
         // Only lane 0 of that row matters when the look-ahead fits its 16 bytes (the
         // short stencils): then every lane reads lane 0's bytes -- one broadcast
-        // request instead of a 64-lane row (6 % less read traffic at 8 rows/wave).
+        // request instead of a 64-lane row (1/kGroup less read traffic).
         constexpr bool lane0_only = (2 * (TOUT - 1) + (TIN > 0 ? TIN - 1 : 0)) <= 8;
         const uint32_t nlane = lane0_only ? 0u
                                : next_is_halo ? (lane < DEMOD_HALO_BYTES / 16u ? lane : 0u)
                                               : lane;
 #if DEMOD_EXACT_WAITS
+        // ---- exchange lines in LDS (see LdsExchange) ------------------------
+        constexpr int kExX = 2 * (TIN > 1 ? TIN - 1 : 0);  // floats a lane publishes per row: re, im of its first samples
+        constexpr int kExD = TOUT - 1;                     // ... and its first discriminator outputs
+        __shared__ float lds_x[kWavesPerBlock][2][64 * (kExX > 0 ? kExX : 1)];
+        __shared__ float lds_d[kWavesPerBlock][2][64 * (kExD > 0 ? kExD : 1)];
+        lds_float *wr_x[2], *wr_d[2];
+        const lds_float *rd_x[2], *rd_d[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            wr_x[p] = (lds_float *) &lds_x[wave][p][lane * kExX];
+            wr_d[p] = (lds_float *) &lds_d[wave][p][lane * kExD];
+            rd_x[p] = lane < 63u ? (const lds_float *) &lds_x[wave][p][(lane + 1u) * kExX]
+                                 : (const lds_float *) &lds_x[wave][p ^ 1][0];
+            rd_d[p] = lane < 63u ? (const lds_float *) &lds_d[wave][p][(lane + 1u) * kExD]
+                                 : (const lds_float *) &lds_d[wave][p ^ 1][0];
+        }
         // ---- loads and waits spelled out ------------------------------------
         // hipcc keeps one vmcnt score for loads and stores together and, with
         // both kinds pending, drains it to 0 before any use.  Here every row's
-        // result is stored as soon as it is computed (no result buffer: ~30
-        // fewer VGPRs, 8 wavefronts per SIMD) while later rows' loads are still
+        // result is stored as soon as it is computed (no result buffer, ~30
+        // fewer VGPRs) while later rows' loads are still
         // in flight, so the loads are issued from inline asm (invisible to
         // hipcc) and waited for by count: gfx950 retires vector-memory
         // operations in issue order, and when row k is needed exactly
@@ -515,20 +582,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
             else qn.x = qn1;
             Halo h = halo;
             next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
+            // the first row processed uses line 0 and, in lane 63, slot 0 of line 1
 #pragma unroll
-            for (int j = 0; j < kMaxTaps - 1; ++j) {
-                halo.xr[j] = have_next ? h.xr[j] : kPastEnd;
-                halo.xi[j] = have_next ? h.xi[j] : kPastEnd;
-                halo.d[j] = have_next ? h.d[j] : 0.f;
+            for (int j = 0; j < kExX / 2; ++j) {
+                wr_x[1][2 * j] = have_next ? h.xr[j] : kPastEnd;
+                wr_x[1][2 * j + 1] = have_next ? h.xi[j] : kPastEnd;
             }
+#pragma unroll
+            for (int j = 0; j < TOUT - 1; ++j) wr_d[1][j] = have_next ? h.d[j] : 0.f;
         }
+        float lead = kAtanLead;
+        asm volatile("" : "+v"(lead));  // one register for the whole segment, see fast_atan2
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
             const bool live = re >= rb + 1u + (uint32_t) k;  // wave-uniform
             const uint32_t r = live ? re - 1u - (uint32_t) k : rb;
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
             float y[4];
-            process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, halo, 16, y);
+            LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1]};
+            process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
             // the first lanes of a chunk's first row hold outputs that belong to the
             // chunk-head kernel; rows past a clipped segment are recomputed copies of
             // row rb: both store to the sink so that the store count stays exact
@@ -594,7 +666,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
                 y[k][0] = __uint_as_float(q[k].x); y[k][1] = __uint_as_float(q[k].y);
                 y[k][2] = __uint_as_float(q[k].z); y[k][3] = __uint_as_float(q[k].w);
 #else
-                process_row<TIN, TOUT, COND, false>(q[k], a, halo, 16, y[k]);
+                RegisterExchange ex{halo};
+                process_row<TIN, TOUT, COND, false>(q[k], a, ex, 16, kAtanLead, y[k]);
 #endif
             }
         }
