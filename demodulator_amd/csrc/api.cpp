@@ -283,7 +283,7 @@ static void fill_sections(const Plan &pl, int &sec_in, int &sec_out, float (*sos
 static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, uint64_t n_chunks,
                     uint32_t tail_bytes, float *d_out, hipStream_t stream) {
     const Plan &pl = ctx->plan;
-    const uint64_t stride = 5 * chunk_bytes + 2 * (4 * kMaxSections + 8);
+    const uint64_t stride = 6 * chunk_bytes + 3 * (4 * kMaxSections + 8);
     if (!ctx->tiny_work || ctx->tiny_stride < stride) {
         if (ctx->tiny_work) HIP_TRY(ctx, hipFree(ctx->tiny_work));
         ctx->tiny_work = nullptr;
@@ -299,6 +299,7 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     t.n_chunks = n_chunks;
     t.tail_bytes = tail_bytes;
     fill_sections(pl, t.sec_in, t.sec_out, t.sos_in, t.sos_out, t.scale);
+    t.in_separate = pl.in_separate;
     const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
     const uint32_t threads = (uint32_t) std::min<uint64_t>(total, kTinyThreads);
     if (launch_tiny(t, pl.conditioning, threads, stream)) {
@@ -401,6 +402,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         // head window; only a stream end makes it short
         h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
         fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale);
+        h.in_separate = pl.in_separate;
         if (forked) {
             HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fork_ev, 0));

@@ -44,6 +44,7 @@ struct HeadLaunch {
     uint32_t head_outputs;     // outputs to produce per head (multiple of 4)
     uint32_t last_chunk_bytes; // bytes of the last head's chunk (== chunk_bytes unless ragged tail)
     int sec_in, sec_out;
+    int in_separate;           // Plan::in_separate
     float sos_in[kMaxSections][6];
     float sos_out[kMaxSections][6];
     float scale;
@@ -59,6 +60,7 @@ struct TinyLaunch {
     uint64_t n_chunks;         // full chunks
     uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
     int sec_in, sec_out;
+    int in_separate;           // Plan::in_separate
     float sos_in[kMaxSections][6];
     float sos_out[kMaxSections][6];
     float scale;

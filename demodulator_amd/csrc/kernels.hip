@@ -747,7 +747,9 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
         }
         // cells K .. K+2Si-2 overflow into the output stage's buffer.  Their
         // "input" is the aliased head of the complex stage's own output
-        // (x[K + t] == z[t]); the last 2Si-1 iterations (u = 0 .. 2Si-2) write them.
+        // (x[K + t] == z[t]) -- or zeros when the stage reads a buffer of its
+        // own (-q2); the last 2Si-1 iterations (u = 0 .. 2Si-2) write them.
+        const bool own = a.in_separate == 0;
         float ovr[2 * (kFixed ? SI : kMaxSections) + 1], ovi[2 * (kFixed ? SI : kMaxSections) + 1];
 #pragma unroll
         for (int t = 0; t <= 2 * Si; ++t) ovr[t] = ovi[t] = 0.f;
@@ -760,9 +762,9 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
                 const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
                 const float a0 = a.sos_in[m][3], a1 = a.sos_in[m][4], a2 = a.sos_in[m][5];
                 float v = b0 * ovr[t] + b1 * ovr[t + 1] + 1.0f;
-                ovr[t] = v - (a0 + a1 * zr[t] + a2 * zr[t + 1]);
+                ovr[t] = v - (a0 + a1 * (own ? zr[t] : 0.f) + a2 * (own ? zr[t + 1] : 0.f));
                 v = b0 * ovi[t] + b1 * ovi[t + 1];
-                ovi[t] = v - (a0 + a1 * zi[t] + a2 * zi[t + 1]);
+                ovi[t] = v - (a0 + a1 * (own ? zi[t] : 0.f) + a2 * (own ? zi[t + 1] : 0.f));
             }
         }
 #pragma unroll
@@ -825,11 +827,14 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
         float *dem = F + 4 * a.chunk_bytes + kTinyPad;
         for (uint64_t i = 0; i < a.work_stride; ++i) F[i] = 0.f;
 
-        for (uint32_t i = 0; i < B; ++i) F[i] = unpack_byte<COND>(bytes[i], a.scale);
+        // -q2: the complex stage reads highpassDc's own buffer (zeros behind it)
+        // and writes where the unpacked samples would otherwise be
+        float *X = a.in_separate ? dem + a.chunk_bytes + kTinyPad : F;
+        for (uint32_t i = 0; i < B; ++i) X[i] = unpack_byte<COND>(bytes[i], a.scale);
         float *src = F;
         float *y2 = F + B;
         if (Si > 0) {
-            float *x = F, *y = F + B;  // x[B + t] aliases y[t], exactly as in the reference
+            float *x = X, *y = a.in_separate ? F : F + B;  // -L: x[B + t] aliases y[t], exactly as in the reference
             for (uint32_t i = 0; i < B; i += 2) {
                 for (int m = 0; m < Si; ++m) {
                     const uint32_t n = i + 2 * Si + 2 * m;
@@ -841,8 +846,8 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
                     y[n + 1] = t - (a0 + a1 * x[n + 1] + a2 * x[n + 3]);
                 }
             }
-            src = F + B;
-            y2 = F + 2 * B;
+            src = y;
+            y2 = y + B;
         }
         for (uint32_t n = 0; n < Ld; ++n)
             dem[n] = discriminate_literal(src[4 * n], src[4 * n + 1], src[4 * n + 2], src[4 * n + 3]);

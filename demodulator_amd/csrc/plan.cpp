@@ -166,8 +166,14 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
         err = "demod mode 0 (raw filtered IQ output, src/matrix.c:244-251) is not part of this path";
         return false;
     }
-    if (iq_mode == 1 || iq_mode == 2) {
-        err = "-q1 (correctIq) and -q2 (highpassDc) IQ conditioning are not supported";
+    if (iq_mode == 1) {
+        err = "-q1 (correctIq, src/matrix.c:120-140) carries state from chunk to chunk and is not part of "
+              "this path";
+        return false;
+    }
+    if (iq_mode == 2 && (o.lowpass_in != 0 || in_degree != 0)) {
+        err = "-q2 (highpassDc) together with -L needs two complex filters in a row, which this path does "
+              "not have: use one or the other";
         return false;
     }
     if (o.buf_size < 4 || (o.buf_size & (o.buf_size - 1))) {
@@ -194,13 +200,19 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
     plan = Plan{};
     plan.chunk_bytes = o.buf_size;
     plan.conditioning = iq_mode == 3 ? kNormalize : kShiftOrigin;
-    plan.prefilter = in_degree != 0;
+    plan.prefilter = in_degree != 0 || iq_mode == 2;
+    plan.in_separate = iq_mode == 2;
 
     plan.out.sections = (int) ((o.out_degree + 1) / 2);
     design_sections(o.mode & 1, o.out_degree, o.lowpass_out, o.sample_rate, o.epsilon,
                     plan.out.sos);  // src/matrix.c:224-225
     derive_taps(plan.out);
-    if (plan.prefilter) {
+    if (iq_mode == 2) {
+        // highpassDc: Butterworth highpass, degree 3, 1 Hz, in front of the discriminator
+        plan.in.sections = 2;
+        design_sections(2, 3, 1.L, o.sample_rate, 0.L, plan.in.sos);  // src/matrix.c:151
+        derive_taps(plan.in);
+    } else if (plan.prefilter) {
         plan.in.sections = (int) ((in_degree + 1) / 2);
         design_sections((o.mode >> 1) & 1, in_degree, o.lowpass_in, o.sample_rate, o.epsilon,
                         plan.in.sos);  // src/matrix.c:229-230

@@ -43,7 +43,11 @@ struct Plan {
     uint64_t chunk_bytes = 0;  // B
     int conditioning = kShiftOrigin;
     bool prefilter = false;
-    Stage in;    // complex input filter (-L), sections == 0 when absent
+    // -q2: the complex stage is highpassDc (src/matrix.c:142-157), which reads a
+    // buffer of its own: zeros behind the chunk's last sample where the -L filter
+    // reads the head of its own output (the two buffers are adjacent there).
+    bool in_separate = false;
+    Stage in;    // complex input filter (-L, or the -q2 highpass), sections == 0 when absent
     Stage out;   // real output filter (-l)
     int head_outputs = 0;  // H: outputs per chunk that the closed form does not cover
     int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row that leave their store to the head kernel

@@ -251,8 +251,10 @@ typedef struct {
     size_t sec_in, sec_out; /* SOS rows */
     int prefilter;          /* complex input filter enabled */
     int normalize;          /* -q3 unpack instead of shiftOrigin */
+    int highpass;           /* -q2: highpassDc in front of everything else */
     float (*sos_in)[6];
     float (*sos_out)[6];
+    float sos_hp[2][6];     /* src/matrix.c:147,151 */
 } plan_t;
 
 static int make_plan(const orc_params *p, plan_t *pl) {
@@ -262,7 +264,7 @@ static int make_plan(const orc_params *p, plan_t *pl) {
 
     memset(pl, 0, sizeof *pl);
     if (!demod_mode) return -1;            /* src/matrix.c:244-251, unreachable from the CLI */
-    if (iq_mode == 1 || iq_mode == 2) return -1; /* correctIq / highpassDc: out of scope */
+    if (iq_mode == 1) return -1;           /* correctIq: state carried across chunks, out of scope */
     if (!p->out_degree || !p->buf_size || (p->buf_size & 3)) return -1;
     /* src/matrix.c:190-192 */
     if (p->lowpass_in != 0 && !in_degree) in_degree = p->out_degree;
@@ -272,6 +274,9 @@ static int make_plan(const orc_params *p, plan_t *pl) {
 
     pl->chunk = p->buf_size;
     pl->normalize = (iq_mode == 3);
+    pl->highpass = (iq_mode == 2);
+    /* src/matrix.c:151: Butterworth highpass, degree 3, 1 Hz, epsilon 0 */
+    if (pl->highpass) orc_design_sos(2, 3, 1.L, p->sample_rate, 0.L, pl->sos_hp);
     pl->prefilter = in_degree != 0;
     pl->sec_out = orc_sections(p->out_degree);
     pl->sec_in = orc_sections(in_degree);
@@ -291,9 +296,17 @@ static void free_plan(plan_t *pl) {
     free(pl->sos_out);
 }
 
+/* highpassDc's private buffer is B floats (src/matrix.c:152) and its filter
+ * reads up to 4S+3 = 11 floats past it.  In the reference that is the rest of
+ * the calloc'ed mapping (zeros for the chunk sizes the CLI can reach with mmap'ed
+ * allocations, >= 32 KiB chunks; heap contents otherwise -- undefined there,
+ * zeros here). */
+#define HP_PAD 16
+
 typedef struct {
     float *work;   /* filterRet: 2B floats, or 4B with the prefilter (src/matrix.c:186-187,228,234) */
     float *demod;  /* demodRet: B floats, only [0, B/4) ever written (src/matrix.c:184) */
+    float *hp;     /* highpassDc's static buf, -q2 only */
     size_t work_len;
 } scratch_t;
 
@@ -301,12 +314,14 @@ static int make_scratch(const plan_t *pl, scratch_t *s) {
     s->work_len = (pl->chunk << 1) << (pl->prefilter ? 1 : 0);
     s->work = calloc(s->work_len, sizeof(float));
     s->demod = calloc(pl->chunk, sizeof(float));
-    return (s->work && s->demod) ? 0 : -1;
+    s->hp = pl->highpass ? calloc(pl->chunk + HP_PAD, sizeof(float)) : NULL;
+    return (s->work && s->demod && (s->hp || !pl->highpass)) ? 0 : -1;
 }
 
 static void free_scratch(scratch_t *s) {
     free(s->work);
     free(s->demod);
+    free(s->hp);
 }
 
 /* One iteration of the consumer loop, src/matrix.c:253-272, on `len` bytes
@@ -318,7 +333,16 @@ static void run_chunk(const plan_t *pl, scratch_t *s, const uint8_t *bytes, size
     const size_t B = len;
     const size_t n_out = B >> 2;
 
-    if (pl->normalize)
+    if (pl->highpass) {
+        /* highpassDc, src/matrix.c:142-157: shiftOrigin into its own buffer, then
+         * the complex filter from there into filterRet; the 4S-2 floats the
+         * filter writes past its B outputs land in filterRet + B, the next
+         * stage's buffer.  (A short tail chunk, this build's tail policy, sees
+         * zeros behind its last sample, not the previous chunk's samples.) */
+        orc_unpack_shift(bytes, B, s->hp);
+        memset(s->hp + B, 0, (pl->chunk + HP_PAD - B) * sizeof(float));
+        orc_filter_complex(s->hp, F, B, 2, (const float(*)[6]) pl->sos_hp);
+    } else if (pl->normalize)
         orc_unpack_normalize(bytes, B, F);
     else
         orc_unpack_shift(bytes, B, F);

@@ -46,6 +46,11 @@ void ref_filter_complex(float *x, float *y, size_t len, size_t sections,
  * sequence, the reference's own functions.  Full chunks only (the reference's
  * tail handling is racy).  Returns floats written or
  * -1 for option sets the harness does not drive. */
+/* -q2 in THIS function is only meaningful in a fresh process: highpassDc keeps
+ * a static buffer sized by its first call and static coefficients
+ * (src/matrix.c:147-153), and what its filter reads behind that buffer depends
+ * on the allocator's state.  oracle/__init__.py therefore runs -q2 streams
+ * through oracle/_ref/ref_stream (ref_stream_main.c), one process per stream. */
 long long ref_process_stream(const orc_params *p, const uint8_t *in, size_t n_bytes,
                              float *out) {
     const size_t B = p->buf_size;
@@ -61,9 +66,10 @@ long long ref_process_stream(const orc_params *p, const uint8_t *in, size_t n_by
     float *work, *dem;
     size_t c;
 
-    if (!demodMode || iqMode == 1 || iqMode == 2) return -1;
+    if (!demodMode || iqMode == 1) return -1;
     if (inDegree && p->lowpass_in == 0) return -1;
-    unpack = iqMode == 3 ? normalizeInput : shiftOrigin;
+    unpack = iqMode == 3 ? normalizeInput : iqMode == 2 ? highpassDc : shiftOrigin;
+    samplingRate = p->sample_rate;  /* src/matrix.c:206 */
 
     {
         REAL sosIn[sosLenIn ? sosLenIn : 1][6];

@@ -72,6 +72,15 @@ STREAM_CASES["D6_d3_L_b4096"] = (flagset(in_degree=6, out_degree=3, lowpass_in=1
 STREAM_CASES["D2_d7_L_b4096"] = (flagset(in_degree=2, out_degree=7, lowpass_in=12500.0,
                                          lowpass_out=6500.0, buf_size=4096), 0xD3300D41, 2)
 
+# -q2 highpassDc conditioning (src/matrix.c:142-157).  Chunks of 32 KiB and more only:
+# below that the reference reads heap contents behind highpassDc's buffer (undefined).
+# The reference runs these in a process of its own (oracle/ref_stream_main.c).
+STREAM_CASES["q2_b32768"] = (flagset(mode=0x18, buf_size=32768), 0xD3300D50, 2)
+STREAM_CASES["q2_d5_S96k_b65536"] = (flagset(mode=0x18, sample_rate=96000.0, out_degree=5,
+                                             buf_size=65536), 0xD3300D51, 2)
+STREAM_CASES["q2_L_b32768"] = (flagset(mode=0x18, lowpass_in=12500.0, lowpass_out=6500.0,
+                                       buf_size=32768), 0xD3300D52, 2)
+
 # known-answer byte quads, SURVEY.md Appendix A.2 (signed zeros, +-pi, wrap of 255)
 QUADS = np.array([
     [127, 127, 122, 124], [127, 127, 132, 130], [127, 127, 127, 127], [127, 130, 127, 120],

@@ -9,8 +9,8 @@ deterministic policy, Appendix B.1):
   with larger taps.  The reference's own FMA vs non-FMA builds differ by up to
   1.43e-6 here.  The sign of +-pi results must match exactly, which this bound
   enforces (a wrong sign is an error of 2*pi*|h|).
-* with -L, or with the -q3 normalizeInput unpack (inputs byte*2/255-1 are not
-  exact, so the reference's separately rounded products and this path's FMAs
+* with -L, with the -q2 highpassDc conditioning (a complex filter like -L's), or
+  with the -q3 normalizeInput unpack (inputs byte*2/255-1 are not exact, so the reference's separately rounded products and this path's FMAs
   can land on opposite sides of the negative real axis):
   |gpu - ref| <= 2e-5 * max(1, |ref|) for >= 99.999 % of the outputs
   and <= 1e-4 * max(1, |ref|) for the rest (reference self-difference: max
@@ -49,9 +49,9 @@ class Report:
 
 
 def inexact_path(lowpass_in: float, mode: int) -> bool:
-    """True when the discriminator arguments are rounded values (-L and/or -q3):
+    """True when the discriminator arguments are rounded values (-L, -q2, -q3):
     selects the wrap-aware criterion."""
-    return lowpass_in != 0 or ((mode >> 2) & 3) == 3
+    return lowpass_in != 0 or ((mode >> 2) & 3) in (2, 3)
 
 
 def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: bool) -> Report:

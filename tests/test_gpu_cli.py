@@ -64,6 +64,22 @@ def test_cli_default_chunk_many_chunks():
     assert compare(got, want, dm.design(opt)["taps"], False).ok
 
 
+def test_cli_highpass_dc_conditioning(manifest, golden):
+    """-q 2 (highpassDc, src/matrix.c:142-157) through the CLI, against the golden
+    vector of the compiled reference."""
+    c = manifest["streams"]["q2_b32768"]
+    opt = dm.Options(**c["flags"])
+    data = oracle.synth_bytes(c["seed"], 0, c["n_chunks"] * opt.buf_size)
+    out = _run([DEMOD, "-i", "-", "-o", "-", "-q", "2", "-b", "-3"], data.tobytes())
+    got = np.frombuffer(out, dtype=np.float32)
+    want = golden(c["file"])
+    assert got.size == want.size
+    assert compare(got, want, dm.design(opt)["taps"], True).ok
+    r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-q", "2", "-L", "12500"], input=b"", stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode != 0 and b"one or the other" in r.stderr
+
+
 def test_cli_rejects_undefined_options():
     r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-D", "3"], input=b"", stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)

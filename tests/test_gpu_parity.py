@@ -87,6 +87,11 @@ def test_golden_streams(manifest, golden):
     for name, case in manifest["streams"].items():
         opt = _opts(case["flags"])
         data = oracle.synth_bytes(case["seed"], 0, case["n_chunks"] * opt.buf_size)
+        if ((opt.mode >> 2) & 3) == 2 and opt.lowpass_in:
+            # -q2 together with -L: pinned for the oracle only, refused by the product
+            with pytest.raises(dm.DemodError, match="one or the other"):
+                dm.Demodulator(opt)
+            continue
         with dm.Demodulator(opt) as d:
             got = d.process_host(data)
         rep = _check(name, got, golden(case["file"]), opt)
@@ -248,7 +253,7 @@ def test_full_size_baseline_configs(orc, flags, seed):
 def test_random_option_sets_and_lengths(orc):
     """Seeded sweep over what the golden files do not pin individually: filter
     degrees 1..16 on both filters (1-5 tap stencils, the generic 5-tap kernel and
-    the scratch-based chunk-head replay), Chebyshev bits, -q3, chunk sizes from
+    the scratch-based chunk-head replay), Chebyshev bits, -q2, -q3, chunk sizes from
     4 B to 64 KiB, ragged stream lengths, segment sizes."""
     import os
     rounds = int(os.environ.get("DEMOD_FUZZ_CASES", "48"))       # soak: DEMOD_FUZZ_CASES=2000
@@ -259,6 +264,8 @@ def test_random_option_sets_and_lengths(orc):
         out_deg = int(rng.integers(1, 17))
         in_deg = int(rng.choice([0, 0, int(rng.integers(1, 17))])) if with_in else 0
         mode = 0x10 | int(rng.choice([0, 0, 1, 2, 3])) | (0xC if rng.random() < 0.2 else 0)
+        if not with_in and rng.random() < 0.2:
+            mode = (mode & ~0xC) | 0x8      # -q2 highpassDc (this path has it without -L only)
         opt = dm.Options(sample_rate=float(rng.choice([96000.0, 125000.0, 192000.0])),
                          lowpass_in=float(rng.choice([9600.0, 12500.0])) if with_in else 0.0,
                          lowpass_out=float(rng.choice([6500.0, 12500.0])),
@@ -396,7 +403,7 @@ def test_argument_errors_are_reported_not_computed():
         with pytest.raises(dm.DemodError):
             d.set_segment_rows(3)
         with pytest.raises(dm.DemodError):
-            d.set_piece_rows(4)
+            d.set_piece_rows(2)                                                          # less than one segment
         d.process_ptr(iq.data_ptr(), 0, out.data_ptr())                                # empty: fine, nothing launched
     with dm.Demodulator(dm.Options(buf_size=64)) as d:
         iq = torch.zeros(1024, dtype=torch.uint8, device="cuda")

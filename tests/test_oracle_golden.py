@@ -106,3 +106,9 @@ def test_against_live_reference(orc):
                           buf_size=int(1 << rng.integers(5, 14)))
         data = rng.integers(0, 256, fl.buf_size * 3, dtype=np.uint8)
         assert np.array_equal(bits(orc.process(fl, data)), bits(ref.process(fl, data))), fl
+    # -q2 highpassDc, alone and in front of -L; chunks of 32 KiB and more (below that the
+    # reference reads heap contents behind its buffer); one reference process per stream
+    for kw in (dict(), dict(lowpass_in=12500.0, lowpass_out=6500.0), dict(out_degree=6, sample_rate=96000.0)):
+        fl = oracle.Flags(mode=0x18, buf_size=1 << 15, **kw)
+        data = rng.integers(0, 256, fl.buf_size * 3, dtype=np.uint8)
+        assert np.array_equal(bits(orc.process(fl, data)), bits(ref.process(fl, data))), fl
