@@ -96,8 +96,8 @@ int demod_abi_version(void);
 /* Create a context on HIP device `device`: designs the filters on the host,
  * derives the stencil taps and uploads nothing until the first process call.
  * Fails with DEMOD_E_INVAL for option sets the reference leaves undefined
- * (-D without -L, src/matrix.c:227-231) or that are out of scope (-q1, -q2,
- * demod mode 0), with a message in demod_last_error(NULL). */
+ * (-D without -L, src/matrix.c:227-231) or that are out of scope (-q1, -q2
+ * together with -L, demod mode 0), with a message in demod_last_error(NULL). */
 int demod_create(const demod_params *p, int device, demod_ctx **out);
 void demod_destroy(demod_ctx *ctx);
 
