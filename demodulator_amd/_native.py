@@ -24,7 +24,8 @@ EXPORTS = (
     "demod_stream_submit", "demod_stream_collect", "demod_alloc_pinned",
     "demod_free_pinned", "demod_alloc_device", "demod_free_device", "demod_copy_to_device",
     "demod_copy_to_host", "demod_synchronize", "demod_get_sos", "demod_get_taps",
-    "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
+    "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_output_format",
+    "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
     "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
     "demod_enable_timing",
 )
@@ -94,6 +95,8 @@ def load() -> C.CDLL:
         "demod_design_query": (i32, [C.POINTER(Params), i32, vp, i32, vp, i32, C.POINTER(C.c_float),
                                      C.POINTER(i32), C.POINTER(i32)]),
         "demod_set_seamless": (i32, [vp, i32]),
+        "demod_set_output_format": (i32, [vp, i32, C.c_float]),
+        "demod_output_bytes": (i32, [vp]),
         "demod_set_segment_rows": (i32, [vp, u32]),
         "demod_set_piece_rows": (i32, [vp, u32]),
         "demod_synth_fill": (i32, [vp, vp, u64, u64, u64, vp]),

@@ -45,6 +45,9 @@ struct demod_ctx {
     bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
     uint32_t seg_rows = 0;  // 0 = automatic
     uint32_t piece_rows = kPieceRows;  // rows per demod_rows dispatch
+    bool out_s16 = false;              // results leave as int16 (demod_set_output_format)
+    float out_scale = 1.f;
+    uint32_t out_bytes() const { return out_s16 ? 2u : 4u; }
     int last_row_launches = 0;  // demod_rows dispatches issued by the most recent process call
 
     // kernel timing (HIP events on the launch stream)
@@ -62,8 +65,8 @@ struct demod_ctx {
     struct Slot {
         void *h_in = nullptr, *h_out = nullptr, *h_halo = nullptr, *d_in = nullptr, *d_out = nullptr, *d_halo = nullptr;
         hipStream_t stream = nullptr;
-        uint64_t out_floats = 0;  // results waiting in h_out
-        float *dst = nullptr;     // where they go
+        uint64_t out_floats = 0;  // results waiting in h_out (count, in the output format)
+        char *dst = nullptr;      // where they go
     } slot[2];
     bool slots_ready = false;
     int submit_slot = 0;   // streaming form: next slot to fill
@@ -205,6 +208,23 @@ int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows) {
     return DEMOD_OK;
 }
 
+int demod_set_output_format(demod_ctx *ctx, int format, float scale) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if ((format != DEMOD_OUT_F32 && format != DEMOD_OUT_S16) || !(scale > 0.f) || !(scale < 3.0e38f)) {
+        ctx->fail(DEMOD_E_INVAL, "output format must be DEMOD_OUT_F32 or DEMOD_OUT_S16 with a positive finite scale");
+        return DEMOD_E_INVAL;
+    }
+    if (ctx->in_flight) {
+        ctx->fail(DEMOD_E_INVAL, "output format cannot change while submitted pieces are uncollected");
+        return DEMOD_E_INVAL;
+    }
+    ctx->out_s16 = format == DEMOD_OUT_S16;
+    ctx->out_scale = scale;
+    return DEMOD_OK;
+}
+
+int demod_output_bytes(const demod_ctx *ctx) { return ctx ? (int) ctx->out_bytes() : DEMOD_E_INVAL; }
+
 int demod_set_seamless(demod_ctx *ctx, int on) {
     if (!ctx) return DEMOD_E_INVAL;
     ctx->seamless = on != 0;
@@ -281,7 +301,7 @@ static void fill_sections(const Plan &pl, int &sec_in, int &sec_out, float (*sos
 }
 
 static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, uint64_t n_chunks,
-                    uint32_t tail_bytes, float *d_out, hipStream_t stream) {
+                    uint32_t tail_bytes, void *d_out, hipStream_t stream) {
     const Plan &pl = ctx->plan;
     const uint64_t stride = 6 * chunk_bytes + 3 * (4 * kMaxSections + 8);
     if (!ctx->tiny_work || ctx->tiny_stride < stride) {
@@ -300,6 +320,8 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     t.tail_bytes = tail_bytes;
     fill_sections(pl, t.sec_in, t.sec_out, t.sos_in, t.sos_out, t.scale);
     t.in_separate = pl.in_separate;
+    t.out_s16 = ctx->out_s16;
+    t.out_scale = ctx->out_scale;
     const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
     const uint32_t threads = (uint32_t) std::min<uint64_t>(total, kTinyThreads);
     if (launch_tiny(t, pl.conditioning, threads, stream)) {
@@ -314,7 +336,8 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     if (!ctx) return DEMOD_E_INVAL;
     if (n_bytes == 0) return DEMOD_OK;
     const uint8_t *d_in = static_cast<const uint8_t *>(d_in_v);
-    float *d_out = static_cast<float *>(d_out_v);
+    char *d_out = static_cast<char *>(d_out_v);
+    const uint64_t ob = ctx->out_bytes();  // bytes per output
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const Plan &pl = ctx->plan;
     // seamless mode: one chunk as long as any stream (2 TiB); only whether the
@@ -393,7 +416,9 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     if (n_heads && pl.head_quads) {
         HeadLaunch h{};
         h.in = d_in + first_head;
-        h.out = d_out + first_head / 4;
+        h.out = d_out + first_head / 4 * ob;
+        h.out_s16 = ctx->out_s16;
+        h.out_scale = ctx->out_scale;
         h.chunk_bytes = B;
         h.n_heads = n_heads;
         h.head_outputs = 4u * (uint32_t) pl.head_quads;
@@ -427,6 +452,8 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         r.seg_log2 = seg_log2;
         r.head_quads = (uint32_t) pl.head_quads;
         fill_stencils(pl, r);
+        r.out_s16 = ctx->out_s16;
+        r.out_scale = ctx->out_scale;
 
         ctx->last_row_launches = 0;
         const uint32_t ragged = (uint32_t) (row_bytes & (kRowBytes - 1));
@@ -470,7 +497,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
                     split, (uint64_t) p0 + ctx->piece_rows - ((phase + p0) & (seg_rows - 1u)));
                 RowLaunch a = r;
                 a.in = d_in + (uint64_t) p0 * kRowBytes;
-                a.out = d_out + (uint64_t) p0 * kRowOutputs;
+                a.out = d_out + (uint64_t) p0 * kRowOutputs * ob;
                 a.n_rows = p1 - p0;
                 a.rows_readable = readable - p0;
                 a.phase_rows = (uint32_t) (((uint64_t) phase + p0) & ((1ull << rpc_log2) - 1));
@@ -487,7 +514,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         if (ragged) {
             RowLaunch a = r;
             a.in = d_in + (uint64_t) split * kRowBytes;
-            a.out = d_out + (uint64_t) split * kRowOutputs;
+            a.out = d_out + (uint64_t) split * kRowOutputs * ob;
             a.n_rows = total_rows - split;
             a.rows_readable = a.n_rows;
             a.phase_rows = (uint32_t) (((offset + (uint64_t) split * kRowBytes) % B) / kRowBytes);
@@ -507,7 +534,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     if (forked) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->join_ev, 0));
 
     if (tiny_tail) {
-        const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4, stream);
+        const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4 * ob, stream);
         if (rc) return rc;
     }
     return DEMOD_OK;
@@ -535,13 +562,14 @@ static int ensure_slots(demod_ctx *ctx) {
 static int drain_slot(demod_ctx *ctx, demod_ctx::Slot &s) {
     if (!s.out_floats) return DEMOD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    memcpy(s.dst, s.h_out, s.out_floats * sizeof(float));
+    memcpy(s.dst, s.h_out, s.out_floats * ctx->out_bytes());
     s.out_floats = 0;
     return DEMOD_OK;
 }
 
-int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, float *h_out,
+int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, void *h_out_v,
                        const demod_span *span) {
+    char *h_out = static_cast<char *>(h_out_v);
     if (!ctx) return DEMOD_E_INVAL;
     if (n_bytes == 0) return DEMOD_OK;
     if (!h_in_v || !h_out || (n_bytes & 3)) {
@@ -599,9 +627,9 @@ int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, flo
         HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, len, hipMemcpyHostToDevice, s.stream));
         rc = demod_process_device(ctx, s.d_in, len, s.d_out, &sp, s.stream);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, len, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, len / 4 * ctx->out_bytes(), hipMemcpyDeviceToHost, s.stream));
         s.out_floats = len / 4;
-        s.dst = h_out + done / 4;
+        s.dst = h_out + done / 4 * ctx->out_bytes();
         done += len;
         which ^= 1;
     }
@@ -638,7 +666,7 @@ int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, cons
     HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, n_bytes, hipMemcpyHostToDevice, s.stream));
     rc = demod_process_device(ctx, s.d_in, n_bytes, s.d_out, &sp, s.stream);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, n_bytes, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, n_bytes / 4 * ctx->out_bytes(), hipMemcpyDeviceToHost, s.stream));
     s.out_floats = n_bytes / 4;
     s.dst = nullptr;
     ctx->submit_slot ^= 1;
@@ -646,7 +674,7 @@ int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, cons
     return DEMOD_OK;
 }
 
-int demod_stream_collect(demod_ctx *ctx, const float **out, uint64_t *n_floats) {
+int demod_stream_collect(demod_ctx *ctx, const void **out, uint64_t *n_floats) {
     if (!ctx || !out || !n_floats) return DEMOD_E_INVAL;
     *out = nullptr;
     *n_floats = 0;
@@ -654,7 +682,7 @@ int demod_stream_collect(demod_ctx *ctx, const float **out, uint64_t *n_floats) 
     demod_ctx::Slot &s = ctx->slot[ctx->collect_slot];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    *out = static_cast<const float *>(s.h_out);
+    *out = s.h_out;
     *n_floats = s.out_floats;
     s.out_floats = 0;
     ctx->collect_slot ^= 1;

@@ -55,10 +55,10 @@ static int wait_full(demod_consumer_args *args) {
 }
 
 static void drain(demod_ctx *dm, FILE *out) {
-    const float *res = NULL;
+    const void *res = NULL;
     uint64_t n = 0;
     if (demod_stream_collect(dm, &res, &n) != DEMOD_OK) die("collect", demod_last_error(dm));
-    if (n) fwrite(res, sizeof(float), n, out);
+    if (n) fwrite(res, (size_t) demod_output_bytes(dm), n, out);
 }
 
 void *processMatrix(void *ctx) {
@@ -87,6 +87,15 @@ void *processMatrix(void *ctx) {
     if (demod_create(&p, 0, &dm) != DEMOD_OK) die("cannot start the MI355X demodulation path", demod_last_error(NULL));
     if (chunk > demod_stream_capacity()) die("chunk size", "larger than the staging capacity of the streaming host path");
 
+    {
+        /* DEMOD_OUT_S16=<scale>: write signed 16-bit samples, clamp(y * scale, -1, 1) * 32767
+         * (demod_set_output_format); not reference behaviour */
+        const char *env_s16 = getenv("DEMOD_OUT_S16");
+        if (env_s16 && env_s16[0]) {
+            const float scale = strtof(env_s16, NULL);
+            if (demod_set_output_format(dm, DEMOD_OUT_S16, scale) != DEMOD_OK) die("DEMOD_OUT_S16", demod_last_error(dm));
+        }
+    }
     if (seamless) {
         if (demod_set_seamless(dm, 1) != DEMOD_OK) die("seamless", demod_last_error(dm));
         held = malloc(chunk ? chunk : 1);

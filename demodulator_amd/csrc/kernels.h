@@ -17,7 +17,7 @@ uint32_t max_segment_rows();
 // Main streaming kernel: rows [0, n_rows) of a device buffer.
 struct RowLaunch {
     const uint8_t *in;
-    float *out;
+    void *out;             // float32, or int16 when out_s16
     const uint8_t *halo;   // DEMOD_HALO_BYTES that follow the buffer in the stream (device), or null
     float *sink;           // 1 KiB of device scratch that swallows the stores of chunk-head lanes
     uint32_t n_rows;       // rows this launch computes; the last one may be ragged
@@ -32,13 +32,17 @@ struct RowLaunch {
     float fold_re, fold_im;  // constant terms of the complex stencil with the unpack's -128 folded in
     float hout[kMaxTaps];
     float scale;           // normalizeInput: (float)(2./255.)
+    uint32_t out_s16;      // results leave as int16: clamp(y * out_scale, -1, 1) * 32767 rounded (host side: picks the build)
+    float out_scale;
 };
 
 // Chunk-head kernel: literal replay of the sectioned recurrences over the first
 // few samples of every chunk that starts inside the buffer.
 struct HeadLaunch {
     const uint8_t *in;         // first byte of the first chunk head
-    float *out;                // its first output
+    void *out;                 // its first output (float32 or int16, see RowLaunch)
+    int out_s16;
+    float out_scale;
     uint64_t chunk_bytes;      // distance between heads
     uint32_t n_heads;
     uint32_t head_outputs;     // outputs to produce per head (multiple of 4)
@@ -53,7 +57,9 @@ struct HeadLaunch {
 // Whole-chunk literal kernel for chunks smaller than one row (B < 1024).
 struct TinyLaunch {
     const uint8_t *in;
-    float *out;
+    void *out;
+    int out_s16;
+    float out_scale;
     float *work;               // per-thread scratch, work_stride floats each
     uint64_t work_stride;
     uint64_t chunk_bytes;

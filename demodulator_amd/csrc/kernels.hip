@@ -417,6 +417,33 @@ __device__ __forceinline__ void store_out16(float *dst, const float (&y)[4]) {
 #endif
 }
 
+// int16 output (DEMOD_OUT_S16): one signed-normalised conversion per pair,
+// v_cvt_pknorm_i16_f32: clamp(y * scale, -1, 1) * 32767, rounded to nearest.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t to_s16_pair(float lo, float hi, float scale) {
+    const s16x2 p = __builtin_amdgcn_cvt_pknorm_i16(lo * scale, hi * scale);
+    return (uint32_t) (uint16_t) p.x | ((uint32_t) (uint16_t) p.y << 16);
+}
+__device__ __forceinline__ int16_t to_s16(float v, float scale) {
+    return (int16_t) (to_s16_pair(v, 0.f, scale) & 0xFFFFu);
+}
+__device__ __forceinline__ void store_out8_s16(void *dst, const float (&y)[4], float scale) {
+    u32x2 v;
+    v.x = to_s16_pair(y[0], y[1], scale);
+    v.y = to_s16_pair(y[2], y[3], scale);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(dst));
+}
+// Four results of one lane to element `index` of the output, in the output's format.
+template <bool S16>
+__device__ __forceinline__ void store_quad(void *dst, const float (&y)[4], float scale) {
+    if constexpr (S16) store_out8_s16(dst, y, scale);
+    else store_out16(static_cast<float *>(dst), y);
+}
+template <bool S16>
+__device__ __forceinline__ char *out_address(void *base, uint64_t index) {
+    return static_cast<char *>(base) + index * (S16 ? 2u : 4u);
+}
+
 // 16 bytes of a ragged row: only `valid` (multiple of 4) bytes exist.
 __device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint32_t lane, int valid) {
     const uint32_t *p = reinterpret_cast<const uint32_t *>(row_base) + 4 * lane;
@@ -434,7 +461,7 @@ __device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint
 #ifndef DEMOD_MIN_WAVES_PER_SIMD
 #define DEMOD_MIN_WAVES_PER_SIMD 1
 #endif
-template <int TIN, int TOUT, int COND, bool RAGGED>
+template <int TIN, int TOUT, int COND, bool RAGGED, bool S16>
 __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -486,14 +513,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
             const int valid = lane_valid(r);
             process_row<TIN, TOUT, COND, true>(load(r), a, ex, valid, kAtanLead, y);
             const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
-            float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
+            char *dst = out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane);
             if (!head) {
                 if (valid >= 16) {
-                    store_out16(dst, y);
+                    store_quad<S16>(dst, y, a.out_scale);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (4 * j < valid) dst[j] = y[j];
+                        if (4 * j < valid) {
+                            if constexpr (S16) reinterpret_cast<int16_t *>(dst)[j] = to_s16(y[j], a.out_scale);
+                            else reinterpret_cast<float *>(dst)[j] = y[j];
+                        }
                 }
             }
         }
@@ -604,14 +634,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
             // the first lanes of a chunk's first row hold outputs that belong to the
             // chunk-head kernel; rows past a clipped segment are recomputed copies of
             // row rb: both store to the sink so that the store count stays exact
-            float *dst = a.out + (uint64_t) r * kRowOutputs + 4u * lane;
+            char *dst = out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane);
             if ((((g0 + r) & rpc_mask) == 0u) || !live) {  // wave-uniform, rare
                 const bool to_sink = !live || lane < a.head_quads;
-                dst = to_sink ? a.sink + 4u * lane : dst;
+                dst = to_sink ? reinterpret_cast<char *>(a.sink + 4u * lane) : dst;
             }
-            store_out16(dst, y);
+            store_quad<S16>(dst, y, a.out_scale);
         }
 #else
+        static_assert(!S16, "the int16 output exists in the DEMOD_EXACT_WAITS build only");
         // only the dwords the look-ahead reads are loaded (a wider load whose
         // upper registers are dead makes hipcc wait for it before reusing them)
         uint4 qn = make_uint4(0, 0, 0, 0);
@@ -680,9 +711,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
                 // the chunk-head kernel
                 const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
 #if defined(DEMOD_EXP_NOMEM)
-                if (!head && y[k][0] == 123456.789f) store_out16(a.out + 4u * lane, y[k]);  // keeps the results live
+                if (!head && y[k][0] == 123456.789f) store_out16(static_cast<float *>(a.out) + 4u * lane, y[k]);  // keeps the results live
 #else
-                if (!head) store_out16(a.out + (uint64_t) r * kRowOutputs + 4u * lane, y[k]);
+                if (!head) store_out16(static_cast<float *>(a.out) + (uint64_t) r * kRowOutputs + 4u * lane, y[k]);
 #endif
             }
         }
@@ -709,7 +740,7 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.n_heads) return;
     const uint8_t *bytes = a.in + (uint64_t) c * a.chunk_bytes;
-    float *out = a.out + (uint64_t) c * (a.chunk_bytes >> 2);
+    const uint64_t out0 = (uint64_t) c * (a.chunk_bytes >> 2);  // element index of this chunk's first output
     const uint32_t chunk = (c == a.n_heads - 1) ? a.last_chunk_bytes : (uint32_t) a.chunk_bytes;
     const int K = (int) (chunk >> 1);   // complex samples in this chunk
     const int Ld = (int) (chunk >> 2);  // outputs of this chunk
@@ -799,7 +830,11 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
     }
 #pragma unroll
     for (int n = 0; n < H; n += 4)
-        *reinterpret_cast<float4 *>(out + n) = make_float4(yc[n], yc[n + 1], yc[n + 2], yc[n + 3]);
+    {
+        const float q[4] = {yc[n], yc[n + 1], yc[n + 2], yc[n + 3]};
+        if (a.out_s16) store_quad<true>(out_address<true>(a.out, out0 + n), q, a.out_scale);
+        else store_quad<false>(out_address<false>(a.out, out0 + n), q, a.out_scale);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -818,7 +853,7 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
     for (uint64_t c = tid; c < total; c += nthreads) {
         const uint32_t B = c < a.n_chunks ? (uint32_t) a.chunk_bytes : a.tail_bytes;
         const uint8_t *bytes = a.in + c * a.chunk_bytes;
-        float *out = a.out + c * (a.chunk_bytes >> 2);
+        const uint64_t out0 = c * (a.chunk_bytes >> 2);
         const uint32_t Ld = B >> 2;
         // same buffer layout as the reference (src/matrix.c:184-187,228,234):
         // work = 2B floats (4B with the input filter) and a separate B-float
@@ -860,7 +895,13 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
                 y2[n] = t - (a0 + a1 * dem[n] + a2 * dem[n + 1]);
             }
         }
-        for (uint32_t n = 0; n < Ld; ++n) out[n] = y2[n];
+        if (a.out_s16) {
+            int16_t *out = static_cast<int16_t *>(a.out) + out0;
+            for (uint32_t n = 0; n < Ld; ++n) out[n] = to_s16(y2[n], a.out_scale);
+        } else {
+            float *out = static_cast<float *>(a.out) + out0;
+            for (uint32_t n = 0; n < Ld; ++n) out[n] = y2[n];
+        }
     }
 }
 
@@ -903,10 +944,17 @@ int launch_rows_t(const RowLaunch &a, hipStream_t s) {
     const uint32_t segs = ((g1 + (1u << a.seg_log2) - 1u) >> a.seg_log2) - (g0 >> a.seg_log2);
     const uint32_t blocks = (segs + (uint32_t) kWavesPerBlock - 1u) / (uint32_t) kWavesPerBlock;
     const dim3 threads(64 * kWavesPerBlock);
-    if (a.ragged_bytes)
-        hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, true>), dim3(blocks), threads, 0, s, a);
-    else
-        hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false>), dim3(blocks), threads, 0, s, a);
+    if (a.out_s16) {
+        if (a.ragged_bytes)
+            hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, true, true>), dim3(blocks), threads, 0, s, a);
+        else
+            hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false, true>), dim3(blocks), threads, 0, s, a);
+    } else {
+        if (a.ragged_bytes)
+            hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, true, false>), dim3(blocks), threads, 0, s, a);
+        else
+            hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false, false>), dim3(blocks), threads, 0, s, a);
+    }
     return hip_ok(hipGetLastError());
 }
 

@@ -137,6 +137,19 @@ class Demodulator:
         boundaries); chunk_offset then counts from the start of the stream."""
         self._check(self._lib.demod_set_seamless(self._ctx, 1 if on else 0), "demod_set_seamless")
 
+    def set_output_format(self, fmt: str = "f32", scale: float = 1.0) -> None:
+        """"f32" (the reference's output) or "s16": clamp(y * scale, -1, 1) * 32767
+        rounded to nearest, the float -> signed 16-bit hop of the reference's README
+        pipes fused into the kernel's store (demod_set_output_format)."""
+        if fmt not in ("f32", "s16"):
+            raise DemodError("output format must be 'f32' or 's16'")
+        self._check(self._lib.demod_set_output_format(self._ctx, 1 if fmt == "s16" else 0, scale),
+                    "demod_set_output_format")
+
+    @property
+    def output_dtype(self):
+        return np.int16 if self._lib.demod_output_bytes(self._ctx) == 2 else np.float32
+
     def set_piece_rows(self, rows: int) -> None:
         self._check(self._lib.demod_set_piece_rows(self._ctx, rows), "demod_set_piece_rows")
 
@@ -154,18 +167,19 @@ class Demodulator:
 
     def process(self, iq, out=None, *, chunk_offset: int = 0, halo=None, end_of_stream: bool = True):
         """iq: 1-D torch.uint8 CUDA tensor of interleaved I,Q bytes.  Returns a
-        torch.float32 CUDA tensor with iq.numel() // 4 results.  Runs on torch's
-        current stream."""
+        torch.float32 (int16 after set_output_format("s16")) CUDA tensor with
+        iq.numel() // 4 results.  Runs on torch's current stream."""
         import torch
 
+        odt = torch.int16 if self.output_dtype == np.int16 else torch.float32
         if not (iq.is_cuda and iq.dtype == torch.uint8 and iq.is_contiguous()):
             raise DemodError("process() needs a contiguous CUDA uint8 tensor")
         n = iq.numel()
         if out is None:
-            out = torch.empty(n // 4, dtype=torch.float32, device=iq.device)
-        elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+            out = torch.empty(n // 4, dtype=odt, device=iq.device)
+        elif not (out.is_cuda and out.dtype == odt and out.is_contiguous()
                   and out.numel() >= n // 4):
-            raise DemodError("out must be a contiguous CUDA float32 tensor of numel >= n // 4")
+            raise DemodError(f"out must be a contiguous CUDA {odt} tensor of numel >= n // 4")
         halo_ptr = 0
         if halo is not None:
             if not (halo.is_cuda and halo.dtype == torch.uint8 and halo.numel() >= _native.HALO_BYTES):
@@ -180,7 +194,7 @@ class Demodulator:
                      end_of_stream: bool = True) -> np.ndarray:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         n = data.size - (data.size & 3)
-        out = np.empty(n // 4, dtype=np.float32)
+        out = np.empty(n // 4, dtype=self.output_dtype)
         hp = None
         if halo is not None:
             halo = np.ascontiguousarray(halo, dtype=np.uint8)

@@ -105,7 +105,7 @@ void demod_destroy(demod_ctx *ctx);
 const char *demod_last_error(const demod_ctx *ctx);
 
 /* HOT PATH.  Demodulate n_bytes of uint8 IQ resident in device memory at d_in
- * into n_bytes/4 float32 at d_out, asynchronously on `stream` (a hipStream_t
+ * into n_bytes/4 float32 (or int16, see demod_set_output_format) at d_out, asynchronously on `stream` (a hipStream_t
  * passed as void*, NULL = default stream).  d_in must be 16-byte aligned,
  * d_out 16-byte aligned, n_bytes a multiple of 4.  span == NULL means: buffer
  * starts on a chunk boundary and the stream ends with it.
@@ -118,7 +118,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in, uint64_t n_bytes, voi
  * h_in in pieces through pinned staging buffers with hipMemcpyAsync on two
  * streams, runs the hot path, downloads to h_out; returns when h_out is
  * complete.  Same span semantics as above (halo is a HOST pointer here). */
-int demod_process_host(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, float *h_out,
+int demod_process_host(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, void *h_out,
                        const demod_span *span);
 
 /* Pipelined form of the host path for a producer/consumer loop (CLI, backend
@@ -131,7 +131,7 @@ int demod_process_host(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, float
  * output.  submit returns DEMOD_E_INVAL if both slots are still uncollected. */
 uint64_t demod_stream_capacity(void);
 int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, const demod_span *span);
-int demod_stream_collect(demod_ctx *ctx, const float **out, uint64_t *n_floats);
+int demod_stream_collect(demod_ctx *ctx, const void **out, uint64_t *n_outputs);
 
 /* Pinned host memory (the reference's allocateBuffer hook,
  * src/matrix.c:282-285 / cuda/matrix.cu:106-109). */
@@ -167,6 +167,20 @@ int demod_design_query(const demod_params *p, int which, float *rows6, int max_r
  * offset from the START OF THE STREAM (0 or any multiple of 1024) and every
  * buffer but the last needs span.halo. */
 int demod_set_seamless(demod_ctx *ctx, int on);
+
+/* Output format (not reference behaviour; float32 by default).  DEMOD_OUT_S16
+ * fuses the float32 -> signed 16-bit hop that follows the reference in its
+ * README pipes (`sox -ef -b32 ... -es -b16`, README.md:22,29) into the kernel's
+ * store: every result leaves as clamp(y * scale, -1, 1) * 32767 rounded to
+ * nearest, 2 bytes per output instead of 4 (d_out / h_out / collect then hold
+ * int16_t; 3 instead of 4 bytes of HBM traffic per IQ sample).  scale = 1
+ * clips at +-1 rad as sox does with the reference's output; 1 / (pi * sum |h_out|)
+ * maps the discriminator's full range onto the full int16 range.
+ * demod_output_bytes: size of one output in the current format (4 or 2). */
+#define DEMOD_OUT_F32 0
+#define DEMOD_OUT_S16 1
+int demod_set_output_format(demod_ctx *ctx, int format, float scale);
+int demod_output_bytes(const demod_ctx *ctx);
 
 /* Tuning knob: rows (1 KiB of input each) a wavefront streams through before
  * it needs a fresh look-ahead; power of two, 0 = automatic. */

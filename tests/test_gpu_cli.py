@@ -80,6 +80,23 @@ def test_cli_highpass_dc_conditioning(manifest, golden):
     assert r.returncode != 0 and b"one or the other" in r.stderr
 
 
+def test_cli_int16_output_env():
+    """DEMOD_OUT_S16=<scale> makes the CLI (through libdemod_backend.so) write signed
+    16-bit samples: the stated conversion of what it writes without it."""
+    import os
+    opt = dm.Options(buf_size=16384)
+    data = oracle.synth_bytes(0x517, 0, 4 * opt.buf_size + 400)
+    f32 = np.frombuffer(_run([DEMOD, "-i", "-", "-o", "-", "-b", "-4"], data.tobytes()), dtype=np.float32)
+    r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-b", "-4"], input=data.tobytes(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120, env={**os.environ, "DEMOD_OUT_S16": "0.125"})
+    assert r.returncode == 0, r.stderr.decode()
+    s16 = np.frombuffer(r.stdout, dtype=np.int16)
+    assert s16.size == f32.size == data.size // 4
+    want = np.rint(np.clip(f32 * np.float32(0.125), -1, 1).astype(np.float64) * 32767.0).astype(np.int16)
+    diff = np.abs(s16.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-3 * diff.size + 1
+
+
 def test_cli_rejects_undefined_options():
     r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-D", "3"], input=b"", stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)

@@ -382,6 +382,55 @@ def test_launch_pieces_do_not_change_results(flags):
         assert np.array_equal(np.concatenate([ref_a, ref_b]).view(np.uint32), ref_whole.view(np.uint32))
 
 
+def _s16_model(y: np.ndarray, scale: float) -> np.ndarray:
+    """demod_set_output_format(DEMOD_OUT_S16): clamp(y * scale, -1, 1) * 32767, rounded to nearest."""
+    v = np.clip(y.astype(np.float32) * np.float32(scale), np.float32(-1), np.float32(1))
+    return np.rint(v.astype(np.float64) * 32767.0).astype(np.int16)
+
+
+@pytest.mark.parametrize("flags", [C2, C3, dict(buf_size=64), dict(lowpass_in=12500.0, lowpass_out=6500.0, out_degree=7,
+                                                                  in_degree=6, buf_size=4096)],
+                         ids=["C2", "C3", "b64", "d7D6"])
+def test_int16_output_is_the_converted_float_output(flags):
+    """The fused int16 store (not reference behaviour: it replaces the sox hop of
+    README.md:22,29; parity with sox itself is unpinned, sox is not in the image):
+    same arithmetic as the float32 path, so every int16 result must be the stated
+    conversion of the float32 result the same call produces -- device path, host
+    path, ragged tail, chunk heads, seamless mode and shard cuts included."""
+    import torch
+    opt = dm.Options(**flags)
+    n = 3 * opt.buf_size + (1000 if opt.buf_size >= 1024 else 0)
+    data = oracle.synth_bytes(0x516, 0, n)
+    n4 = n & ~3
+    for scale in (1.0, 1.0 / (np.pi * float(np.abs(dm.design(opt)["taps"]).sum()))):
+        with dm.Demodulator(opt) as f32, dm.Demodulator(opt) as s16:
+            s16.set_output_format("s16", scale)
+            iq = torch.from_numpy(data[:n4]).cuda()
+            want = _s16_model(f32.process(iq).cpu().numpy(), scale)
+            got = s16.process(iq)
+            assert got.dtype == torch.int16 and got.numel() == n4 // 4
+            got = got.cpu().numpy()
+            diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+            assert diff.max() <= 1 and np.count_nonzero(diff) <= 1e-3 * diff.size + 1, (scale, diff.max(), np.count_nonzero(diff))
+            host = s16.process_host(data)
+            assert host.dtype == np.int16 and np.array_equal(host, got)
+            if opt.buf_size >= 1024:
+                # shard cut inside a chunk, with halo; then the seamless form
+                cut = opt.buf_size + 3 * 1024
+                a = s16.process(iq[:cut].clone(), halo=iq[cut:cut + 64].clone(), end_of_stream=False)
+                b = s16.process(iq[cut:].clone(), chunk_offset=cut % opt.buf_size)
+                assert np.array_equal(torch.cat([a, b]).cpu().numpy(), got)
+                f32.set_seamless(True)
+                s16.set_seamless(True)
+                want_s = _s16_model(f32.process(iq).cpu().numpy(), scale)
+                got_s = s16.process(iq).cpu().numpy()
+                d2 = np.abs(got_s.astype(np.int32) - want_s.astype(np.int32))
+                assert d2.max() <= 1 and np.count_nonzero(d2) <= 1e-3 * d2.size + 1
+    with dm.Demodulator(opt) as d:
+        with pytest.raises(dm.DemodError):
+            d.set_output_format("s16", 0.0)
+
+
 def test_argument_errors_are_reported_not_computed():
     """Misuse of the C ABI returns DEMOD_E_INVAL with a message (no partial work)."""
     import torch
