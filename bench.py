@@ -21,7 +21,11 @@ are NOT chunk boundaries (every shard starts 96 KiB into a 256 KiB chunk), so
 each rank needs the 64 look-ahead bytes that follow its shard: they are
 exchanged every step with RCCL send/recv (torch.distributed P2P, backend
 "nccl" = RCCL over xGMI) inside the timed region.  --aligned cuts at chunk
-boundaries instead (no exchange is needed then, and none is made).
+boundaries instead (no exchange is needed then, and none is made).  Barriers,
+the max over ranks and one vote run over a gloo control group; the vote follows
+one untimed exchange under a watchdog: if RCCL point-to-point does not come up
+on the node, the run falls back to chunk-aligned cuts and says so in
+config.sharding instead of hanging.
 
 Before the W warm-up steps every rank spins the device up for --prewarm-ms
 (default 300 ms) of the same work, as part of set-up: a fresh process runs its
@@ -101,8 +105,34 @@ def cpu_baseline(sample_log2: int, flags: dict, seed: int, fetch=None) -> dict:
     return res
 
 
+def _exchange_works(torch, dist, fn, timeout_s: float = 90.0) -> bool:
+    """One untimed halo exchange under a watchdog, then a vote over the (gloo)
+    control group: True only if it completed on every rank.  The point-to-point
+    path over RCCL is the one part of this benchmark that cannot be rehearsed on a
+    one-GPU box; if it does not come up on the node, the run falls back to
+    chunk-aligned cuts (which need no exchange) instead of hanging."""
+    import threading
+
+    state = {"ok": False}
+
+    def probe():
+        try:
+            fn()
+            torch.cuda.synchronize()
+            state["ok"] = True
+        except Exception as e:  # noqa: BLE001
+            state["err"] = repr(e)
+
+    t = threading.Thread(target=probe, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    flag = torch.tensor([1 if (state["ok"] and not t.is_alive()) else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int, world: int,
-                 aligned: bool, seg_rows: int, prewarm_ms: float = 300.0):
+                 aligned: bool, seg_rows: int, prewarm_ms: float = 300.0, data_group=None):
     wl = WORKLOADS[name]
     n_bytes = 2 << wl["log2_samples"]  # per GPU
     opt = dm.Options(**wl["flags"])
@@ -128,17 +158,30 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     d.synth_fill(iq, me.start, wl["seed"])  # this rank's bytes of the global stream
     halo = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device=dev)
 
-    def step():
+    def exchange():
         if me.needs_halo or me.sends_halo:
             # RCCL send/recv: my first 64 bytes go to the rank on my left, the
             # first 64 bytes of the rank on my right come to me
-            if dist.get_backend() == "nccl":
-                exchange_halo(me, right, iq, halo)
-            else:  # rehearsal backend: through host memory
+            if data_group is not None:
+                exchange_halo(me, right, iq, halo, group=data_group)
+            else:  # rehearsal: through host memory over the control group
                 mine = iq[: dm.HALO_BYTES].cpu()
                 theirs = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8)
                 exchange_halo(me, right, mine, theirs)
                 halo.copy_(theirs)
+
+    fell_back = False
+    if world > 1 and phase and not _exchange_works(torch, dist, exchange):
+        # no exchange on this node: cut at chunk boundaries instead (reference-aligned shards)
+        fell_back = True
+        phase = 0
+        shards = plan_shards(n_bytes * world, world, B, phase_bytes=0)
+        me = shards[rank]
+        right = shards[rank + 1] if rank + 1 < world else None
+        d.synth_fill(iq, me.start, wl["seed"])
+
+    def step():
+        exchange()
         d.process(iq, out, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
                   end_of_stream=me.end_of_stream)
 
@@ -172,7 +215,8 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     del iq, out
     torch.cuda.empty_cache()
     return dict(dt=dt, kernel_ms=kms, launches=launches, n_bytes=n_bytes, opt=opt, checksum=checksum,
-                phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches)
+                phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches,
+                fell_back=fell_back)
 
 
 def main() -> None:
@@ -206,19 +250,24 @@ def main() -> None:
     # DEMOD_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
     # (ranks share devices, the 64-byte halos travel through host memory); never for reported numbers
     backend = os.environ.get("DEMOD_BENCH_BACKEND", "nccl")
+    data_group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", torch.cuda.current_device()))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # control plane (barriers, the max over ranks, the fallback vote) on gloo;
+        # the data path -- the 64-byte look-ahead of every cut -- on RCCL
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl" and not args.aligned:
+            try:
+                data_group = dist.new_group(backend="nccl")
+            except Exception:  # noqa: BLE001
+                data_group = None
+                args.aligned = True
 
     r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
-                     args.segment_rows, args.prewarm_ms)
+                     args.segment_rows, args.prewarm_ms, data_group)
     dt = r["dt"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -244,7 +293,9 @@ def main() -> None:
             "chunk_bytes": r["chunk"],
             "sharding": ("1 GPU" if world == 1 else
                          f"{world} contiguous shards, " +
-                         ("chunk-aligned cuts, no exchange" if not r["phase"] else
+                         ("chunk-aligned cuts, no exchange" + (" (the RCCL look-ahead exchange did not come up on "
+                                                                 "this node: fell back)" if r["fell_back"] else "")
+                          if not r["phase"] else
                           f"cuts {r['phase']} B into a chunk, 64-byte look-ahead via "
                           f"{'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} send/recv per step")),
         },
@@ -315,6 +366,9 @@ def main() -> None:
 
     if world > 1:
         dist.barrier()
+        if r["fell_back"]:
+            sys.stdout.flush()
+            os._exit(0)  # a stuck RCCL probe must not keep the process from ending
         dist.destroy_process_group()
 
 
