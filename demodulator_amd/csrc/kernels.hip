@@ -642,7 +642,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
             store_quad<S16>(dst, y, a.out_scale);
         }
 #else
-        static_assert(!S16, "the int16 output exists in the DEMOD_EXACT_WAITS build only");
         // only the dwords the look-ahead reads are loaded (a wider load whose
         // upper registers are dead makes hipcc wait for it before reusing them)
         uint4 qn = make_uint4(0, 0, 0, 0);
@@ -711,9 +710,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
                 // the chunk-head kernel
                 const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
 #if defined(DEMOD_EXP_NOMEM)
-                if (!head && y[k][0] == 123456.789f) store_out16(static_cast<float *>(a.out) + 4u * lane, y[k]);  // keeps the results live
+                if (!head && y[k][0] == 123456.789f)  // keeps the results live
+                    store_quad<S16>(out_address<S16>(a.out, 4u * lane), y[k], a.out_scale);
 #else
-                if (!head) store_out16(static_cast<float *>(a.out) + (uint64_t) r * kRowOutputs + 4u * lane, y[k]);
+                if (!head)
+                    store_quad<S16>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane), y[k], a.out_scale);
 #endif
             }
         }
