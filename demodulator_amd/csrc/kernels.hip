@@ -611,7 +611,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
             else if constexpr (nx > 2) { qn.x = qn2.x; qn.y = qn2.y; }
             else qn.x = qn1;
             Halo h = halo;
+#ifndef DEMOD_EXP_NO_LOOKAHEAD   // experiment: a segment whose look-ahead costs nothing (wrong results)
             next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
+#else
+            h.d[0] = __uint_as_float(qn.x);
+#endif
             // the first row processed uses line 0 and, in lane 63, slot 0 of line 1
 #pragma unroll
             for (int j = 0; j < kExX / 2; ++j) {
