@@ -996,6 +996,7 @@ int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.n_rows == 0) return 0;
     if (conditioning == kNormalize) return launch_rows_c<kNormalize>(a, taps_in, taps_out, s);
+    if (conditioning == kShiftOriginPlain) return launch_rows_c<kShiftOriginPlain>(a, taps_in, taps_out, s);
     return launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s);
 }
 

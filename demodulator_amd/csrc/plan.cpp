@@ -199,7 +199,7 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
 
     plan = Plan{};
     plan.chunk_bytes = o.buf_size;
-    plan.conditioning = iq_mode == 3 ? kNormalize : kShiftOrigin;
+    plan.conditioning = iq_mode == 3 ? kNormalize : iq_mode == 2 ? kShiftOriginPlain : kShiftOrigin;
     plan.prefilter = in_degree != 0 || iq_mode == 2;
     plan.in_separate = iq_mode == 2;
 

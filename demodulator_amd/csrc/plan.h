@@ -29,7 +29,11 @@ struct Options {
 
 Options options_from_params(const demod_params &p);
 
-enum Conditioning : int { kShiftOrigin = 0, kNormalize = 3 };
+// kShiftOriginPlain: the shiftOrigin unpack without folding its -128 into the complex
+// stencil's constant (kernels.hip, fold_unpack): the -q2 highpass taps (+3, -1) cancel for
+// samples with x[k+1] = 3 x[k], and there the result has to be as precise as the samples are
+// small, not as 128 + sample is.
+enum Conditioning : int { kShiftOrigin = 0, kShiftOriginPlain = 1, kNormalize = 3 };
 
 struct Stage {
     int sections = 0;                 // S = ceil(degree / 2)

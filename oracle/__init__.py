@@ -181,6 +181,21 @@ def restatement() -> _Lib:
     return _cache["orc"]
 
 
+def restatement_fma() -> _Lib | None:
+    """The restatement compiled with FMA contraction (what the reference's IS_NATIVE build
+    does on an FMA machine), or None when this CPU has no FMA."""
+    if "fma" not in _cache:
+        path = os.path.join(_HERE, "libdemod_oracle_fma.so")
+        try:
+            has_fma = " fma " in open("/proc/cpuinfo").read().replace("\n", " ")
+        except OSError:
+            has_fma = False
+        if has_fma and not os.path.exists(path):
+            subprocess.run(["make", "-C", _HERE, "libdemod_oracle_fma.so"], check=False, stdout=subprocess.DEVNULL)
+        _cache["fma"] = _Lib(path, "orc") if has_fma and os.path.exists(path) else None
+    return _cache["fma"]
+
+
 def reference() -> _Lib | None:
     """The real reference compiled from /root/reference, or None when neither
     the sources nor a prebuilt oracle/_ref are present."""

@@ -54,8 +54,55 @@ def inexact_path(lowpass_in: float, mode: int) -> bool:
     return lowpass_in != 0 or ((mode >> 2) & 3) in (2, 3)
 
 
-def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: bool) -> Report:
-    """prefilter: use the wrap-aware (inexact-arithmetic) criterion, see inexact_path()."""
+def conditioning_slack(data: np.ndarray, chunk_bytes: int, taps_in, bias_im: float, taps_out,
+                       ulps: float = 8.0) -> np.ndarray:
+    """Extra absolute difference allowed per output where the reference's own result is
+    ill-conditioned: the discriminator is the ARGUMENT of z[2n] * conj(z[2n+1]), so an
+    absolute rounding error e in a filtered sample z moves it by e / |z|.  The -q2 highpass
+    taps are (+3, -1) to within 1e-4, so z nearly vanishes wherever x[k+1] = 3 x[k] (and the
+    imaginary lane's -2 cancels too); there the reference's FMA and non-FMA builds differ
+    from each other by 1e-3 and more (measured: 3.3e-3 on the fuzz case that motivated this),
+    and no other implementation can be closer to it than it is to itself.  Model, in
+    float64: z[k] = sum_j h[j] x[k+j] + i*bias (zeros past the chunk end), e[k] = `ulps`
+    float32 ulps of the magnitudes summed, slack[n] = sum_j |h_out[j]| * (e/|z| at 2(n+j)
+    and 2(n+j)+1), capped at pi per discriminator value."""
+    data = np.asarray(data, dtype=np.uint8)
+    n = data.size & ~3
+    x = ((data[:n].astype(np.int32) + 1) & 255) - 128          # shiftOrigin
+    h = np.asarray(taps_in, dtype=np.float64)
+    g = np.abs(np.asarray(taps_out, dtype=np.float64))
+    out = np.zeros(n // 4, dtype=np.float64)
+    pos = 0
+    while pos < n:
+        ln = min(chunk_bytes, n - pos)
+        xc = x[pos:pos + ln].astype(np.float64)
+        k = ln // 2
+        xr = np.concatenate([xc[0::2], np.zeros(len(h))])
+        xi = np.concatenate([xc[1::2], np.zeros(len(h))])
+        zr = sum(h[j] * xr[j:j + k] for j in range(len(h)))
+        zi = sum(h[j] * xi[j:j + k] for j in range(len(h))) + bias_im
+        mag = sum(abs(h[j]) * (np.abs(xr[j:j + k]) + np.abs(xi[j:j + k])) for j in range(len(h))) + abs(bias_im)
+        e = ulps * 2.0 ** -24 * mag
+        turn = np.minimum(np.pi, e / np.maximum(np.hypot(zr, zi), 1e-30))
+        dd = np.concatenate([turn[0::2] + turn[1::2], np.zeros(len(g))])
+        m = ln // 4
+        out[pos // 4:pos // 4 + m] = sum(g[j] * dd[j:j + m] for j in range(len(g)))
+        pos += ln
+    return out
+
+
+def q2_slack(dm, opt, data) -> np.ndarray | None:
+    """conditioning_slack for an option set with -q2, None otherwise (dm: the demodulator_amd module)."""
+    if ((opt.mode >> 2) & 3) != 2:
+        return None
+    din = dm.design(opt, "in")
+    return conditioning_slack(data, opt.buf_size, din["taps"], din["bias_im"], dm.design(opt)["taps"])
+
+
+def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: bool,
+            extra_abs: np.ndarray | None = None) -> Report:
+    """prefilter: use the wrap-aware (inexact-arithmetic) criterion, see inexact_path().
+    extra_abs: per-output absolute allowance on top of it (conditioning_slack)."""
     gpu = np.asarray(gpu, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert gpu.shape == ref.shape, (gpu.shape, ref.shape)
@@ -65,6 +112,9 @@ def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: b
     gain = max(1.0, float(np.sum(np.abs(taps_out))) / DEFAULT_GAIN)
     diff = np.abs(gpu - ref)
     scale = np.maximum(1.0, np.abs(ref))
+    if extra_abs is not None:
+        # judged on what exceeds the allowance
+        diff = np.maximum(0.0, diff - np.asarray(extra_abs, dtype=np.float64))
     rel = diff / scale
     finite = np.isfinite(gpu)
     if not prefilter:
@@ -92,7 +142,7 @@ def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: b
                 still_bad.append(int(i))
                 continue
             d = gpu[i] - ref[i]
-            if np.min(np.abs(combos - d)) <= loose * scale[i]:
+            if np.min(np.abs(combos - d)) <= loose * scale[i] + (float(extra_abs[i]) if extra_abs is not None else 0.0):
                 n_wrap += 1
             else:
                 still_bad.append(int(i))

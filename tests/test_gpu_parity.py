@@ -6,7 +6,7 @@ import pytest
 
 import demodulator_amd as dm
 import oracle
-from parity import compare, inexact_path
+from parity import compare, inexact_path, q2_slack
 
 pytestmark = pytest.mark.gpu
 
@@ -24,9 +24,10 @@ def _opts(flags: dict) -> dm.Options:
                                                "in_degree", "out_degree", "mode", "buf_size")})
 
 
-def _check(name, got, want, opt):
+def _check(name, got, want, opt, data=None):
     taps = dm.design(opt)["taps"]
-    rep = compare(got, want, taps, inexact_path(opt.lowpass_in, opt.mode))
+    slack = q2_slack(dm, opt, data) if data is not None else None
+    rep = compare(got, want, taps, inexact_path(opt.lowpass_in, opt.mode), slack)
     assert rep.ok, f"{name}: {rep}"
     return rep
 
@@ -94,7 +95,7 @@ def test_golden_streams(manifest, golden):
             continue
         with dm.Demodulator(opt) as d:
             got = d.process_host(data)
-        rep = _check(name, got, golden(case["file"]), opt)
+        rep = _check(name, got, golden(case["file"]), opt, data)
         worst[name] = (rep.max_rel, rep.n_wrap)
     print({k: v for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0])[:5]})
 
@@ -289,7 +290,7 @@ def test_random_option_sets_and_lengths(orc):
         assert got.size == want.size
         if not np.all(np.isfinite(want)):
             continue            # the reference itself overflows on this design (huge taps): nothing to pin
-        rep = compare(got, want, design["taps"], inexact_path(opt.lowpass_in, opt.mode))
+        rep = compare(got, want, design["taps"], inexact_path(opt.lowpass_in, opt.mode), q2_slack(dm, opt, data))
         assert rep.ok, f"{opt} n_bytes={n_bytes}: {rep}"
         n_cases += 1
     assert n_cases >= min(30, rounds // 2)
