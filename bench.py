@@ -132,7 +132,7 @@ def _exchange_works(torch, dist, fn, timeout_s: float = 90.0) -> bool:
 
 
 def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int, world: int,
-                 aligned: bool, seg_rows: int, prewarm_ms: float = 300.0, data_group=None):
+                 aligned: bool, seg_rows: int, prewarm_ms: float = 300.0, data_group=None, place: bool = True):
     wl = WORKLOADS[name]
     n_bytes = 2 << wl["log2_samples"]  # per GPU
     opt = dm.Options(**wl["flags"])
@@ -154,7 +154,16 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     s16 = wl.get("out") == "s16"
     if s16:
         d.set_output_format("s16", 1.0 / (3.14159265 * float(abs(d.taps("out")[0]).sum())))
-    out = torch.empty(n_bytes // 4, dtype=torch.int16 if s16 else torch.float32, device=dev)
+    # The output buffer is placed inside a slightly larger allocation: input byte i is read
+    # while output byte i is written, so how the two buffers sit relative to each other in
+    # the HBM channel/bank interleave matters on some devices of the pool (tools/skew_probe.py:
+    # up to 7 % between the best and the worst offset on one box, nothing on another).  Set-up
+    # below tries a few offsets, untimed, and keeps the best.
+    odt = torch.int16 if s16 else torch.float32
+    esz = 2 if s16 else 4
+    slack = 48 << 20
+    big = torch.empty(n_bytes // 4 + slack // esz, dtype=odt, device=dev)
+    out = big[: n_bytes // 4]
     d.synth_fill(iq, me.start, wl["seed"])  # this rank's bytes of the global stream
     halo = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device=dev)
 
@@ -194,6 +203,20 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
         d.process(iq, out, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
                   end_of_stream=me.end_of_stream)
         torch.cuda.synchronize()
+    out_skew = 0
+    if place:
+        d.kernel_ms()
+        best = None
+        for skew in (0, 32 << 10, 128 << 10, 1 << 20, 16 << 20, 34 << 20):
+            cand = big[skew // esz: skew // esz + n_bytes // 4]
+            for _ in range(4):
+                d.process(iq, cand, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
+                          end_of_stream=me.end_of_stream)
+            torch.cuda.synchronize()
+            ms, _n = d.kernel_ms()
+            if best is None or ms < best[0] * 0.995:   # move only for a gain beyond the noise
+                best = (ms, skew, cand)
+        out_skew, out = best[1], best[2]
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -212,11 +235,11 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     dispatches = max(1, d.last_call_launches)
     checksum = float(out[1000003:: max(1, out.numel() // 4099)].double().abs().sum().item())
     d.close()
-    del iq, out
+    del iq, out, big
     torch.cuda.empty_cache()
     return dict(dt=dt, kernel_ms=kms, launches=launches, n_bytes=n_bytes, opt=opt, checksum=checksum,
                 phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches,
-                fell_back=fell_back)
+                fell_back=fell_back, out_skew=out_skew)
 
 
 def main() -> None:
@@ -231,6 +254,8 @@ def main() -> None:
                     help="untimed device spin-up before the warm-up steps (set-up, see run_workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-placement", action="store_true",
+                    help="keep the output buffer where the allocator put it (no offset trial at set-up)")
     args = ap.parse_args()
 
     import torch
@@ -264,7 +289,7 @@ def main() -> None:
                 args.aligned = True
 
     r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
-                     args.segment_rows, args.prewarm_ms, data_group)
+                     args.segment_rows, args.prewarm_ms, data_group, not args.no_placement)
     dt = r["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -291,6 +316,7 @@ def main() -> None:
             "workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}",
             "samples_per_gpu": samples_per_gpu,
             "chunk_bytes": r["chunk"],
+            "output_offset_bytes": r["out_skew"],
             "sharding": ("1 GPU" if world == 1 else
                          f"{world} contiguous shards, " +
                          ("chunk-aligned cuts, no exchange" + (" (the RCCL look-ahead exchange did not come up on "
@@ -339,7 +365,7 @@ def main() -> None:
                     continue
                 bps = 3 if WORKLOADS[name].get("out") == "s16" else ALGO_BYTES_PER_SAMPLE
                 x = run_workload(dm, torch, dist, name, max(5, args.steps), 2, 0, 1, True, args.segment_rows,
-                                 args.prewarm_ms)
+                                 args.prewarm_ms, None, not args.no_placement)
                 sp = x["n_bytes"] // 2
                 steps = max(5, args.steps)
                 a = bps * sp / (x["kernel_ms"] * 1e-3)  # per step (1 dispatch at 2^30 samples)
