@@ -458,8 +458,12 @@ __device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint
 // ---------------------------------------------------------------------------
 // the fused streaming kernel
 // ---------------------------------------------------------------------------
+// Register budget: 8 wavefronts per SIMD (64 VGPRs).  The common stencils fit without
+// spilling (56-62 VGPRs; 68 without the hint, i.e. 7 wavefronts) and one more resident
+// wavefront is worth 1.5-2.5 % (profiles/r1_ab_rows_per_wave.txt); the 5-tap generic build
+// does not fit and keeps what it needs (the hint does not force spills).
 #ifndef DEMOD_MIN_WAVES_PER_SIMD
-#define DEMOD_MIN_WAVES_PER_SIMD 1
+#define DEMOD_MIN_WAVES_PER_SIMD 8
 #endif
 template <int TIN, int TOUT, int COND, bool RAGGED, bool S16>
 __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
