@@ -278,21 +278,23 @@ double demod_kernel_ms(demod_ctx *ctx, int *launches) {
 
 static void fill_stencils(const Plan &pl, RowLaunch &r) {
     for (int j = 0; j < kMaxTaps; ++j) {
-        r.hin[j] = pl.in.h[j];
+        r.hin[j] = pl.stencil_in.h[j];
         r.hout[j] = pl.out.h[j];
     }
-    r.bias_im = pl.in.bias_im;
+    r.bias_im = pl.stencil_in.bias_im;
     {
         double sum = 0.0;
-        for (int j = 0; j < pl.in.taps; ++j) sum += (double) pl.in.h[j];
+        for (int j = 0; j < pl.stencil_in.taps; ++j) sum += (double) pl.stencil_in.h[j];
         r.fold_re = (float) (-128.0 * sum);
-        r.fold_im = (float) ((double) pl.in.bias_im - 128.0 * sum);
+        r.fold_im = (float) ((double) pl.stencil_in.bias_im - 128.0 * sum);
     }
     r.scale = (float) (2. / 255.);
 }
 
 static void fill_sections(const Plan &pl, int &sec_in, int &sec_out, float (*sos_in)[6],
-                          float (*sos_out)[6], float &scale) {
+                          float (*sos_out)[6], float &scale, int &sec_pre, float (*sos_pre)[6]) {
+    sec_pre = pl.pre.sections;
+    memcpy(sos_pre, pl.pre.sos, 2 * 6 * sizeof(float));
     sec_in = pl.in.sections;
     sec_out = pl.out.sections;
     memcpy(sos_in, pl.in.sos, sizeof pl.in.sos);
@@ -318,7 +320,7 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     t.chunk_bytes = chunk_bytes;
     t.n_chunks = n_chunks;
     t.tail_bytes = tail_bytes;
-    fill_sections(pl, t.sec_in, t.sec_out, t.sos_in, t.sos_out, t.scale);
+    fill_sections(pl, t.sec_in, t.sec_out, t.sos_in, t.sos_out, t.scale, t.sec_pre, t.sos_pre);
     t.in_separate = pl.in_separate;
     t.out_s16 = ctx->out_s16;
     t.out_scale = ctx->out_scale;
@@ -426,7 +428,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         // a last chunk that continues past the buffer is a full chunk for the
         // head window; only a stream end makes it short
         h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
-        fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale);
+        fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale, h.sec_pre, h.sos_pre);
         h.in_separate = pl.in_separate;
         if (forked) {
             HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, stream));
@@ -503,7 +505,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
                 a.phase_rows = (uint32_t) (((uint64_t) phase + p0) & ((1ull << rpc_log2) - 1));
                 a.ragged_bytes = 0;
                 if (ragged || p1 < split) a.halo = nullptr;  // only the buffer's last rows can need the shard halo
-                if (launch_rows(a, pl.in.taps, pl.out.taps, pl.conditioning, stream)) {
+                if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, pl.conditioning, stream)) {
                     ctx->fail(DEMOD_E_HIP, "demod_rows launch", hipGetLastError());
                     return DEMOD_E_HIP;
                 }
@@ -520,7 +522,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             a.phase_rows = (uint32_t) (((offset + (uint64_t) split * kRowBytes) % B) / kRowBytes);
             a.ragged_bytes = ragged;
             a.halo = nullptr;
-            if (launch_rows(a, pl.in.taps, pl.out.taps, pl.conditioning, stream)) {
+            if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, pl.conditioning, stream)) {
                 ctx->fail(DEMOD_E_HIP, "demod_rows (ragged) launch", hipGetLastError());
                 return DEMOD_E_HIP;
             }
@@ -742,9 +744,18 @@ int demod_synchronize(demod_ctx *ctx) {
     return DEMOD_OK;
 }
 
+static const Stage &stage_of(const Plan &pl, int which) {
+    return which == 2 ? pl.pre : which ? pl.in : pl.out;
+}
+// the stencil of a stage as the streaming kernel applies it: for the input stage the
+// composition with highpassDc when both are on (Plan::stencil_in)
+static const Stage &stencil_of(const Plan &pl, int which) {
+    return which == 2 ? pl.pre : which ? pl.stencil_in : pl.out;
+}
+
 int demod_get_sos(const demod_ctx *ctx, int which, float *rows6, int max_rows) {
     if (!ctx) return DEMOD_E_INVAL;
-    const Stage &st = which ? ctx->plan.in : ctx->plan.out;
+    const Stage &st = stage_of(ctx->plan, which);
     const int n = std::min(st.sections, max_rows);
     if (rows6)
         for (int r = 0; r < n; ++r) memcpy(rows6 + 6 * r, st.sos[r], 6 * sizeof(float));
@@ -753,7 +764,7 @@ int demod_get_sos(const demod_ctx *ctx, int which, float *rows6, int max_rows) {
 
 int demod_get_taps(const demod_ctx *ctx, int which, float *taps, int max_taps, float *bias_im) {
     if (!ctx) return DEMOD_E_INVAL;
-    const Stage &st = which ? ctx->plan.in : ctx->plan.out;
+    const Stage &st = stencil_of(ctx->plan, which);
     if (taps)
         for (int j = 0; j < std::min(st.taps, max_taps); ++j) taps[j] = st.h[j];
     if (bias_im) *bias_im = st.bias_im;
@@ -768,13 +779,14 @@ int demod_design_query(const demod_params *p, int which, float *rows6, int max_r
     Plan plan;
     std::string err;
     if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
-    const Stage &st = which ? plan.in : plan.out;
+    const Stage &st = stage_of(plan, which);
+    const Stage &sn = stencil_of(plan, which);
     if (rows6)
         for (int r = 0; r < std::min(st.sections, max_rows); ++r) memcpy(rows6 + 6 * r, st.sos[r], 6 * sizeof(float));
     if (taps)
-        for (int j = 0; j < std::min(st.taps, max_taps); ++j) taps[j] = st.h[j];
-    if (bias_im) *bias_im = st.bias_im;
-    if (n_taps) *n_taps = st.taps;
+        for (int j = 0; j < std::min(sn.taps, max_taps); ++j) taps[j] = sn.h[j];
+    if (bias_im) *bias_im = sn.bias_im;
+    if (n_taps) *n_taps = sn.taps;
     if (head_outputs) *head_outputs = plan.head_outputs;
     return st.sections;
 }

@@ -49,6 +49,8 @@ struct HeadLaunch {
     uint32_t last_chunk_bytes; // bytes of the last head's chunk (== chunk_bytes unless ragged tail)
     int sec_in, sec_out;
     int in_separate;           // Plan::in_separate
+    int sec_pre;               // 2 when highpassDc runs in front of the -L stage (Plan::pre), else 0
+    float sos_pre[2][6];
     float sos_in[kMaxSections][6];
     float sos_out[kMaxSections][6];
     float scale;
@@ -67,6 +69,8 @@ struct TinyLaunch {
     uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
     int sec_in, sec_out;
     int in_separate;           // Plan::in_separate
+    int sec_pre;               // Plan::pre
+    float sos_pre[2][6];
     float sos_in[kMaxSections][6];
     float sos_out[kMaxSections][6];
     float scale;

@@ -772,6 +772,56 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
         const int NZ = 2 * W;
 #pragma unroll
         for (int k = 0; k < NZ + 2 * Si + 2; ++k) zr[k] = zi[k] = 0.f;
+
+        // -q2 in front of -L (generic build only): highpassDc's cells come first, computed
+        // from a buffer of its own (zeros behind the chunk); its three overflow cells are
+        // constants of the design and land where the -L stage's output buffer starts
+        // (src/matrix.c:155-156, :260-264: filterRet + bufSize is both)
+        constexpr int kP = kFixed ? 1 : kHeadMaxZ + kMaxSections + 8;
+        float pr[kP], pi[kP];
+        bool pre = false;
+        if constexpr (!kFixed) {
+            pre = a.sec_pre > 0;
+            if (pre) {
+                const int Sp = a.sec_pre;
+                const int NP = NZ + Si + 2;  // the -L stage reads cells up to NZ + Si
+                for (int k = 0; k < NP + Sp + 2; ++k) pr[k] = pi[k] = 0.f;
+                for (int i = 0; i + Sp < NP; ++i) {
+                    for (int m = 0; m < Sp; ++m) {
+                        const int n = i + Sp + m;
+                        const float b0 = a.sos_pre[m][0], b1 = a.sos_pre[m][1];
+                        const float a0 = a.sos_pre[m][3], a1 = a.sos_pre[m][4], a2 = a.sos_pre[m][5];
+                        float t = b0 * pr[n] + b1 * pr[n + 1] + 1.0f;
+                        pr[n] = t - (a0 + a1 * sample(n, 0) + a2 * sample(n + 1, 0));
+                        t = b0 * pi[n] + b1 * pi[n + 1];
+                        pi[n] = t - (a0 + a1 * sample(n, 1) + a2 * sample(n + 1, 1));
+                    }
+                }
+                float hr[2 * 2 + 2] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hi[2 * 2 + 2] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 2 * Sp - 1; ++u) {
+                    for (int m = 0; m < Sp; ++m) {
+                        const int t = u + 1 - Sp + m;  // cell K + t, inputs 0.0f
+                        if (t < 0) continue;
+                        const float b0 = a.sos_pre[m][0], b1 = a.sos_pre[m][1];
+                        const float a0 = a.sos_pre[m][3], a1 = a.sos_pre[m][4], a2 = a.sos_pre[m][5];
+                        float v = b0 * hr[t] + b1 * hr[t + 1] + 1.0f;
+                        hr[t] = v - (a0 + a1 * 0.f + a2 * 0.f);
+                        v = b0 * hi[t] + b1 * hi[t + 1];
+                        hi[t] = v - (a0 + a1 * 0.f + a2 * 0.f);
+                    }
+                }
+                for (int t = 0; t < 2 * Sp - 1; ++t) {
+                    zr[t] = hr[t];
+                    zi[t] = hi[t];
+                }
+            }
+        }
+        auto xin = [&](int n, int lane01) -> float {  // what the -L stage reads as its input
+            if constexpr (!kFixed) {
+                if (pre) return lane01 ? pi[n] : pr[n];
+            }
+            return sample(n, lane01);
+        };
 #pragma unroll
         for (int i = 0; i + Si < NZ; ++i) {  // iteration i finalises cell i + Si
 #pragma unroll
@@ -780,9 +830,9 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
                 const float b0 = a.sos_in[m][0], b1 = a.sos_in[m][1];
                 const float a0 = a.sos_in[m][3], a1 = a.sos_in[m][4], a2 = a.sos_in[m][5];
                 float t = b0 * zr[n] + b1 * zr[n + 1] + 1.0f;
-                zr[n] = t - (a0 + a1 * sample(n, 0) + a2 * sample(n + 1, 0));
+                zr[n] = t - (a0 + a1 * xin(n, 0) + a2 * xin(n + 1, 0));
                 t = b0 * zi[n] + b1 * zi[n + 1];
-                zi[n] = t - (a0 + a1 * sample(n, 1) + a2 * sample(n + 1, 1));
+                zi[n] = t - (a0 + a1 * xin(n, 1) + a2 * xin(n + 1, 1));
             }
         }
         // cells K .. K+2Si-2 overflow into the output stage's buffer.  Their
@@ -873,12 +923,26 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
 
         // -q2: the complex stage reads highpassDc's own buffer (zeros behind it)
         // and writes where the unpacked samples would otherwise be
-        float *X = a.in_separate ? dem + a.chunk_bytes + kTinyPad : F;
+        const bool pre = a.sec_pre > 0;  // -q2 in front of -L: highpassDc from its own buffer into F first
+        float *X = (a.in_separate || pre) ? dem + a.chunk_bytes + kTinyPad : F;
         for (uint32_t i = 0; i < B; ++i) X[i] = unpack_byte<COND>(bytes[i], a.scale);
         float *src = F;
         float *y2 = F + B;
+        if (pre) {
+            for (uint32_t i = 0; i < B; i += 2) {
+                for (int m = 0; m < a.sec_pre; ++m) {
+                    const uint32_t n = i + 2 * a.sec_pre + 2 * m;
+                    const float b0 = a.sos_pre[m][0], b1 = a.sos_pre[m][1];
+                    const float a0 = a.sos_pre[m][3], a1 = a.sos_pre[m][4], a2 = a.sos_pre[m][5];
+                    float t = b0 * F[n] + b1 * F[n + 2] + 1.0f;
+                    F[n] = t - (a0 + a1 * X[n] + a2 * X[n + 2]);
+                    t = b0 * F[n + 1] + b1 * F[n + 3];
+                    F[n + 1] = t - (a0 + a1 * X[n + 1] + a2 * X[n + 3]);
+                }
+            }
+        }
         if (Si > 0) {
-            float *x = X, *y = a.in_separate ? F : F + B;  // -L: x[B + t] aliases y[t], exactly as in the reference
+            float *x = pre ? F : X, *y = a.in_separate ? F : F + B;  // -L: x[B + t] aliases y[t], exactly as in the reference
             for (uint32_t i = 0; i < B; i += 2) {
                 for (int m = 0; m < Si; ++m) {
                     const uint32_t n = i + 2 * Si + 2 * m;
@@ -1009,7 +1073,7 @@ template <int COND>
 void launch_heads_c(const HeadLaunch &a, hipStream_t s) {
     const uint32_t blocks = (a.n_heads + 63u) / 64u;
     const int want_h = 4 * ((std::max(2 * a.sec_out - 1, 4 * a.sec_in - 2) + 3) / 4);
-    const bool std_window = (int) a.head_outputs == want_h;
+    const bool std_window = (int) a.head_outputs == want_h && a.sec_pre == 0;
 #define DEMOD_HEADS_CASE(SI, SO)                                                                   \
     if (std_window && a.sec_in == SI && a.sec_out == SO) {                                         \
         hipLaunchKernelGGL((demod_heads<COND, SI, SO>), dim3(blocks), dim3(64), 0, s, a);          \

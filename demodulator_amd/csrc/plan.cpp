@@ -171,11 +171,7 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
               "this path";
         return false;
     }
-    if (iq_mode == 2 && (o.lowpass_in != 0 || in_degree != 0)) {
-        err = "-q2 (highpassDc) together with -L needs two complex filters in a row, which this path does "
-              "not have: use one or the other";
-        return false;
-    }
+    const bool cascade = iq_mode == 2 && o.lowpass_in != 0;
     if (o.buf_size < 4 || (o.buf_size & (o.buf_size - 1))) {
         err = "chunk size must be a power of two >= 4 bytes";
         return false;
@@ -201,31 +197,59 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
     plan.chunk_bytes = o.buf_size;
     plan.conditioning = iq_mode == 3 ? kNormalize : iq_mode == 2 ? kShiftOriginPlain : kShiftOrigin;
     plan.prefilter = in_degree != 0 || iq_mode == 2;
-    plan.in_separate = iq_mode == 2;
+    plan.in_separate = iq_mode == 2 && !cascade;
 
     plan.out.sections = (int) ((o.out_degree + 1) / 2);
     design_sections(o.mode & 1, o.out_degree, o.lowpass_out, o.sample_rate, o.epsilon,
                     plan.out.sos);  // src/matrix.c:224-225
     derive_taps(plan.out);
     if (iq_mode == 2) {
-        // highpassDc: Butterworth highpass, degree 3, 1 Hz, in front of the discriminator
-        plan.in.sections = 2;
-        design_sections(2, 3, 1.L, o.sample_rate, 0.L, plan.in.sos);  // src/matrix.c:151
-        derive_taps(plan.in);
-    } else if (plan.prefilter) {
+        // highpassDc: Butterworth highpass, degree 3, 1 Hz, in front of everything else
+        Stage &hp = cascade ? plan.pre : plan.in;
+        hp.sections = 2;
+        design_sections(2, 3, 1.L, o.sample_rate, 0.L, hp.sos);  // src/matrix.c:151
+        derive_taps(hp);
+    }
+    if (iq_mode != 2 ? plan.prefilter : cascade) {
         plan.in.sections = (int) ((in_degree + 1) / 2);
         design_sections((o.mode >> 1) & 1, in_degree, o.lowpass_in, o.sample_rate, o.epsilon,
                         plan.in.sos);  // src/matrix.c:229-230
         derive_taps(plan.in);
     }
-    for (const Stage *st : {&plan.in, &plan.out})
+    plan.stencil_in = plan.in;
+    if (cascade) {
+        // At a chunk end the -L stage reads highpassDc's overflow cells where its input
+        // ends; only the first two of those hold complete highpass results (SURVEY.md
+        // Appendix A.4 applied to two stages), so the -L stencil may look ahead two samples.
+        if (plan.in.taps > 3) {
+            err = "-q2 together with -L: the input filter's stencil may look ahead two samples at most "
+                  "(degrees up to about 8)";
+            return false;
+        }
+        Stage &c = plan.stencil_in;
+        c = Stage{};
+        c.sections = plan.in.sections;
+        c.taps = plan.pre.taps + plan.in.taps - 1;
+        double sum_in = 0.0;
+        for (int j = 0; j < plan.in.taps; ++j) sum_in += (double) plan.in.h[j];
+        for (int m = 0; m < c.taps && m < kMaxTaps; ++m) {
+            double acc = 0.0;
+            for (int i = 0; i < plan.pre.taps; ++i) {
+                const int j = m - i;
+                if (j >= 0 && j < plan.in.taps) acc += (double) plan.pre.h[i] * (double) plan.in.h[j];
+            }
+            c.h[m] = (float) acc;
+        }
+        c.bias_im = (float) (sum_in * (double) plan.pre.bias_im + (double) plan.in.bias_im);
+    }
+    for (const Stage *st : {&plan.pre, &plan.in, &plan.out})
         for (int r = 0; r < st->sections; ++r)
             for (int c = 0; c < 6; ++c)
                 if (!std::isfinite(st->sos[r][c])) {
                     err = "filter design produced non-finite coefficients for these options";
                     return false;
                 }
-    if (plan.in.taps > kMaxTaps || plan.out.taps > kMaxTaps) {
+    if (plan.stencil_in.taps > kMaxTaps || plan.out.taps > kMaxTaps) {
         err = "stencil longer than supported";
         return false;
     }

@@ -52,6 +52,13 @@ struct Plan {
     // reads the head of its own output (the two buffers are adjacent there).
     bool in_separate = false;
     Stage in;    // complex input filter (-L, or the -q2 highpass), sections == 0 when absent
+    // -q2 together with -L: highpassDc first (`pre`, a buffer of its own), then the -L filter
+    // (`in`, reading what `pre` wrote).  The literal kernels replay both; the streaming kernel
+    // applies ONE stencil, their composition: taps = pre.h * in.h (convolution),
+    // bias = sum(in.h) * pre.bias_im + in.bias_im.  `stencil_in` is what the streaming kernel
+    // uses in every case (a copy of `in` without `pre`).
+    Stage pre;
+    Stage stencil_in;
     Stage out;   // real output filter (-l)
     int head_outputs = 0;  // H: outputs per chunk that the closed form does not cover
     int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row that leave their store to the head kernel

@@ -96,8 +96,8 @@ int demod_abi_version(void);
 /* Create a context on HIP device `device`: designs the filters on the host,
  * derives the stencil taps and uploads nothing until the first process call.
  * Fails with DEMOD_E_INVAL for option sets the reference leaves undefined
- * (-D without -L, src/matrix.c:227-231) or that are out of scope (-q1, -q2
- * together with -L, demod mode 0), with a message in demod_last_error(NULL). */
+ * (-D without -L, src/matrix.c:227-231) or that are out of scope (-q1, demod
+ * mode 0), with a message in demod_last_error(NULL). */
 int demod_create(const demod_params *p, int device, demod_ctx **out);
 void demod_destroy(demod_ctx *ctx);
 
@@ -148,7 +148,10 @@ int demod_synchronize(demod_ctx *ctx);
 /* Introspection (tests): the designed second-order sections
  * {b0,b1,b2,a0,a1,a2} as float rows, the stencil taps derived from them and
  * the per-chunk head length handled by the chunk-head kernel.
- * which: 0 = output filter, 1 = input filter.  Return the row / tap count. */
+ * which: 0 = output filter, 1 = input filter (-L, or the -q2 highpass when alone), 2 = the -q2
+ * highpass when it runs in front of -L.  Taps of the input filter are those of the stencil
+ * the streaming kernel applies: with -q2 and -L both on, the composition of the two.
+ * Return the row / tap count. */
 int demod_get_sos(const demod_ctx *ctx, int which, float *rows6, int max_rows);
 int demod_get_taps(const demod_ctx *ctx, int which, float *taps, int max_taps, float *bias_im);
 int demod_get_head_outputs(const demod_ctx *ctx);

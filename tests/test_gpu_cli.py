@@ -75,9 +75,13 @@ def test_cli_highpass_dc_conditioning(manifest, golden):
     want = golden(c["file"])
     assert got.size == want.size
     assert compare(got, want, dm.design(opt)["taps"], True, q2_slack(dm, opt, data)).ok
-    r = subprocess.run([DEMOD, "-i", "-", "-o", "-", "-q", "2", "-L", "12500"], input=b"", stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=60)
-    assert r.returncode != 0 and b"one or the other" in r.stderr
+    # ... and in front of -L
+    c = manifest["streams"]["q2_L_b32768"]
+    opt = dm.Options(**c["flags"])
+    data = oracle.synth_bytes(c["seed"], 0, c["n_chunks"] * opt.buf_size)
+    out = _run([DEMOD, "-i", "-", "-o", "-", "-q", "2", "-L", "12500", "-l", "6500", "-b", "-3"], data.tobytes())
+    got = np.frombuffer(out, dtype=np.float32)
+    assert compare(got, golden(c["file"]), dm.design(opt)["taps"], True, q2_slack(dm, opt, data)).ok
 
 
 def test_cli_int16_output_env():

@@ -88,11 +88,6 @@ def test_golden_streams(manifest, golden):
     for name, case in manifest["streams"].items():
         opt = _opts(case["flags"])
         data = oracle.synth_bytes(case["seed"], 0, case["n_chunks"] * opt.buf_size)
-        if ((opt.mode >> 2) & 3) == 2 and opt.lowpass_in:
-            # -q2 together with -L: pinned for the oracle only, refused by the product
-            with pytest.raises(dm.DemodError, match="one or the other"):
-                dm.Demodulator(opt)
-            continue
         with dm.Demodulator(opt) as d:
             got = d.process_host(data)
         rep = _check(name, got, golden(case["file"]), opt, data)
@@ -265,8 +260,8 @@ def test_random_option_sets_and_lengths(orc):
         out_deg = int(rng.integers(1, 17))
         in_deg = int(rng.choice([0, 0, int(rng.integers(1, 17))])) if with_in else 0
         mode = 0x10 | int(rng.choice([0, 0, 1, 2, 3])) | (0xC if rng.random() < 0.2 else 0)
-        if not with_in and rng.random() < 0.2:
-            mode = (mode & ~0xC) | 0x8      # -q2 highpassDc (this path has it without -L only)
+        if rng.random() < 0.2:
+            mode = (mode & ~0xC) | 0x8      # -q2 highpassDc, alone or in front of -L
         opt = dm.Options(sample_rate=float(rng.choice([96000.0, 125000.0, 192000.0])),
                          lowpass_in=float(rng.choice([9600.0, 12500.0])) if with_in else 0.0,
                          lowpass_out=float(rng.choice([6500.0, 12500.0])),
