@@ -341,6 +341,8 @@ def main() -> None:
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK, 4) if achieved else None,
             "read_only_frac": round(achieved / 2 / HBM_PEAK, 4) if achieved else None,
+            # MI355X_MICROARCH.md: "HBM3E peak BW 8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)"
+            "frac_of_measured_copy_rate": round(achieved / 6.29e12, 4) if achieved else None,
             "algorithmic_bytes_per_launch": algo,
             "kernel_ms": round(kms, 4),
             "launches_per_step": nd,
