@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "demod_hip.h"
@@ -24,6 +25,28 @@ std::string g_create_error;
 constexpr uint64_t kStageBytes = 32ull << 20;  // host path: input bytes per staged piece
 constexpr uint32_t kTinyThreads = 8192;
 constexpr uint32_t kPieceRows = 1u << 21;       // rows per demod_rows launch (2 GiB of input)
+
+// Host-side staging copy (pageable <-> pinned): one thread moves ~10 GB/s, a PCIe Gen5
+// x16 link twice that in each direction, so large pieces are split over a few threads.
+void staged_copy(void *dst, const void *src, size_t n) {
+    constexpr size_t kMinPerThread = 4u << 20;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = std::min<size_t>({(size_t) 4, n / kMinPerThread, hw ? hw : 1});
+    if (parts < 2) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t step = (n / parts + 4095) & ~(size_t) 4095;
+    for (size_t p = 1; p < parts; ++p) {
+        const size_t off = p * step;
+        if (off >= n) break;
+        const size_t len = std::min(step, n - off);
+        th.emplace_back([=] { memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
+    }
+    memcpy(dst, src, std::min(step, n));
+    for (auto &t : th) t.join();
+}
 
 uint32_t log2u(uint64_t v) {
     uint32_t l = 0;
@@ -564,7 +587,7 @@ static int ensure_slots(demod_ctx *ctx) {
 static int drain_slot(demod_ctx *ctx, demod_ctx::Slot &s) {
     if (!s.out_floats) return DEMOD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    memcpy(s.dst, s.h_out, s.out_floats * ctx->out_bytes());
+    staged_copy(s.dst, s.h_out, s.out_floats * ctx->out_bytes());
     s.out_floats = 0;
     return DEMOD_OK;
 }
@@ -625,7 +648,7 @@ int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, voi
             HIP_TRY(ctx, hipMemcpyAsync(s.d_halo, hh, DEMOD_HALO_BYTES, hipMemcpyHostToDevice, s.stream));
             sp.halo = s.d_halo;
         }
-        memcpy(s.h_in, h_in + done, len);
+        staged_copy(s.h_in, h_in + done, len);
         HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, len, hipMemcpyHostToDevice, s.stream));
         rc = demod_process_device(ctx, s.d_in, len, s.d_out, &sp, s.stream);
         if (rc) return rc;
