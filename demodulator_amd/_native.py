@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DEMOD_HIP_LIBRARY selects another build of the same library (kernel tuning experiments)
 LIB_PATH = os.environ.get("DEMOD_HIP_LIBRARY") or os.path.join(_HERE, "libdemod_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 HALO_BYTES = 64
 ROW_BYTES = 1024
 

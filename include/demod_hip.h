@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMOD_ABI_VERSION 1
+#define DEMOD_ABI_VERSION 2
 
 /* Default chunk size, bytes (include/matrix.h:37-39). */
 #define DEMOD_DEFAULT_BUF_SIZE 262144u
