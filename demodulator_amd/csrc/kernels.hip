@@ -762,8 +762,27 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
 #pragma unroll
     for (int n = 0; n <= W; ++n) yc[n] = 0.f;
 
+    // The window's bytes: the fixed builds fetch them with a few 16-byte loads up front (every
+    // index below is a compile-time constant there, so the unpack reads bytes out of
+    // registers); one byte load per use, 64 cache lines per wave-instruction, was most of this
+    // kernel's time.  A chunk handled here is at least one row long, so the window exists.
+    constexpr int kRawVec = kFixed ? (2 * (kZ + 2) + 15) / 16 : 1;
+    uint32_t raw[4 * kRawVec];
+    if constexpr (kFixed) {
+#pragma unroll
+        for (int v = 0; v < kRawVec; ++v) {
+            const uint4 q = reinterpret_cast<const uint4 *>(bytes)[v];
+            raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w;
+        }
+    }
     auto sample = [&](int k, int lane01) -> float {  // unpacked input, 0.0f past the chunk
-        return k < K ? unpack_byte<COND>(bytes[2 * k + lane01], a.scale) : 0.f;
+        const int i = 2 * k + lane01;
+        if constexpr (kFixed) {
+            const uint8_t b = (uint8_t) (raw[i >> 2] >> (8 * (i & 3)));
+            return k < K ? unpack_byte<COND>(b, a.scale) : 0.f;
+        } else {
+            return k < K ? unpack_byte<COND>(bytes[i], a.scale) : 0.f;
+        }
     };
 
     if (Si > 0) {
