@@ -179,8 +179,15 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
                 exchange_halo(me, right, mine, theirs)
                 halo.copy_(theirs)
 
+    def first_exchange():
+        if data_group is not None:
+            # every rank takes part in one collective first, so that the communicator exists
+            # before the point-to-point messages (which not every rank need send or receive)
+            dist.all_reduce(torch.zeros(1, device=dev), group=data_group)
+        exchange()
+
     fell_back = False
-    if world > 1 and phase and not _exchange_works(torch, dist, exchange):
+    if world > 1 and phase and not _exchange_works(torch, dist, first_exchange):
         # no exchange on this node: cut at chunk boundaries instead (reference-aligned shards)
         fell_back = True
         phase = 0
