@@ -46,6 +46,13 @@ constexpr int kWavesPerBlock = DEMOD_WAVES_PER_BLOCK;  // independent wavefronts
 #ifndef DEMOD_EXACT_WAITS
 #define DEMOD_EXACT_WAITS 1
 #endif
+// Workgroups are handed to the 8 XCDs round-robin.  With 8, the workgroups of a group of
+// eight take interleaved segments (XCD x streams segments x, x+8, x+16, ... of the group's
+// window) instead of eight contiguous 32 KiB pieces: +2-4 % on every box tried
+// (profiles/r1_ab_rows_per_wave.txt); 0 = plain order.
+#ifndef DEMOD_XCD_INTERLEAVE
+#define DEMOD_XCD_INTERLEAVE 8
+#endif
 #ifndef DEMOD_ROWS_PER_WAVE
 #define DEMOD_ROWS_PER_WAVE 4
 #endif
@@ -469,7 +476,15 @@ template <int TIN, int TOUT, int COND, bool RAGGED, bool S16>
 __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if DEMOD_XCD_INTERLEAVE
+    // Consecutive workgroups go to consecutive XCDs: give the kXcd workgroups of a group
+    // interleaved segments, so that each XCD streams every kXcd-th segment of a compact window
+    // instead of a contiguous kWavesPerBlock-segment piece of it.
+    constexpr uint32_t kXcd = DEMOD_XCD_INTERLEAVE;
+    const uint32_t seg = (blockIdx.x / kXcd) * (kXcd * (uint32_t) kWavesPerBlock) + wave * kXcd + blockIdx.x % kXcd;
+#else
     const uint32_t seg = blockIdx.x * (uint32_t) kWavesPerBlock + wave;
+#endif
 
     // rows are numbered from the start of the chunk that encloses buffer row 0
     const uint32_t g0 = a.phase_rows;
@@ -1034,7 +1049,10 @@ template <int TIN, int TOUT, int COND>
 int launch_rows_t(const RowLaunch &a, hipStream_t s) {
     const uint32_t g0 = a.phase_rows, g1 = a.phase_rows + a.n_rows;
     const uint32_t segs = ((g1 + (1u << a.seg_log2) - 1u) >> a.seg_log2) - (g0 >> a.seg_log2);
-    const uint32_t blocks = (segs + (uint32_t) kWavesPerBlock - 1u) / (uint32_t) kWavesPerBlock;
+    uint32_t blocks = (segs + (uint32_t) kWavesPerBlock - 1u) / (uint32_t) kWavesPerBlock;
+#if DEMOD_XCD_INTERLEAVE
+    blocks = (blocks + DEMOD_XCD_INTERLEAVE - 1u) / DEMOD_XCD_INTERLEAVE * DEMOD_XCD_INTERLEAVE;
+#endif
     const dim3 threads(64 * kWavesPerBlock);
     if (a.out_s16) {
         if (a.ragged_bytes)
