@@ -481,7 +481,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
     // interleaved segments, so that each XCD streams every kXcd-th segment of a compact window
     // instead of a contiguous kWavesPerBlock-segment piece of it.
     constexpr uint32_t kXcd = DEMOD_XCD_INTERLEAVE;
+#ifdef DEMOD_XCD_GRAIN   // experiment: contiguous pieces of this many segments per workgroup
+    constexpr uint32_t kGrain = DEMOD_XCD_GRAIN;
+    const uint32_t seg = (blockIdx.x / kXcd) * (kXcd * (uint32_t) kWavesPerBlock) + (wave / kGrain) * (kXcd * kGrain) +
+                         (blockIdx.x % kXcd) * kGrain + wave % kGrain;
+#else
     const uint32_t seg = (blockIdx.x / kXcd) * (kXcd * (uint32_t) kWavesPerBlock) + wave * kXcd + blockIdx.x % kXcd;
+#endif
 #else
     const uint32_t seg = blockIdx.x * (uint32_t) kWavesPerBlock + wave;
 #endif
