@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""GPU box: throughput vs chunk size (-b): small chunks shift work to the chunk-head kernel."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import demodulator_amd as dm
+n = 2 << 29
+iq = torch.empty(n, dtype=torch.uint8, device="cuda"); out = torch.empty(n // 4, dtype=torch.float32, device="cuda")
+for flags in (dict(), dict(lowpass_in=12500.0, lowpass_out=6500.0)):
+    for B in (256, 1024, 4096, 16384, 65536, 262144, 4 << 20):
+        d = dm.Demodulator(dm.Options(buf_size=B, **flags))
+        d.synth_fill(iq, 0, 7)
+        for _ in range(3):
+            d.process(iq, out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            d.process(iq, out)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"{'-L -l' if flags else 'default':8s} chunk {B:>8d} B: {ms:8.3f} ms per 2^29 samples  {n / 2 / ms / 1e3:10.0f} Msamples/s  frac {2 * n / (ms * 1e-3) / 8e12:.3f}")
+        d.close()
