@@ -18,6 +18,9 @@ deterministic policy, Appendix B.1):
   discriminator argument lies within rounding of the negative real axis, +pi and
   -pi are equally valid roundings, and an output may differ by 2*pi*(+-h[j]) or
   a sum of those; such outputs are counted and reported, not failed.
+* -q2 (and, for outliers only, every path with a complex stage in the random sweep): a
+  condition-aware allowance, conditioning_slack() below -- where the filtered sample nearly
+  vanishes the discriminator's argument is rounding noise in the reference itself.
 """
 from __future__ import annotations
 
@@ -55,7 +58,7 @@ def inexact_path(lowpass_in: float, mode: int) -> bool:
 
 
 def conditioning_slack(data: np.ndarray, chunk_bytes: int, taps_in, bias_im: float, taps_out,
-                       ulps: float = 8.0) -> np.ndarray:
+                       ulps: float = 8.0, normalize: bool = False) -> np.ndarray:
     """Extra absolute difference allowed per output where the reference's own result is
     ill-conditioned: the discriminator is the ARGUMENT of z[2n] * conj(z[2n+1]), so an
     absolute rounding error e in a filtered sample z moves it by e / |z|.  The -q2 highpass
@@ -68,7 +71,10 @@ def conditioning_slack(data: np.ndarray, chunk_bytes: int, taps_in, bias_im: flo
     and 2(n+j)+1), capped at pi per discriminator value."""
     data = np.asarray(data, dtype=np.uint8)
     n = data.size & ~3
-    x = ((data[:n].astype(np.int32) + 1) & 255) - 128          # shiftOrigin
+    if normalize:
+        x = data[:n].astype(np.float64) * (2.0 / 255.0) - 1.0  # normalizeInput (-q3)
+    else:
+        x = ((data[:n].astype(np.int32) + 1) & 255) - 128      # shiftOrigin
     h = np.asarray(taps_in, dtype=np.float64)
     g = np.abs(np.asarray(taps_out, dtype=np.float64))
     out = np.zeros(n // 4, dtype=np.float64)
@@ -99,10 +105,26 @@ def q2_slack(dm, opt, data) -> np.ndarray | None:
     return conditioning_slack(data, opt.buf_size, din["taps"], din["bias_im"], dm.design(opt)["taps"])
 
 
+def stage_slack(dm, opt, data) -> np.ndarray | None:
+    """conditioning_slack for any option set with a complex stage (-L and/or -q2), None
+    otherwise.  For -L it is used to adjudicate OUTLIERS only (compare(outlier_abs=...)): with
+    lowpass taps the filtered sample is hundreds of units long almost everywhere, but about one
+    output in 1e8 sits next to zero, and there this path's folded unpack bias (absolute error
+    of a few 1e-5 in the sample) can exceed the loose bound (seen once in 12000 fuzz cases:
+    1.4e-4 against an allowance of 1.6e-3 at that output)."""
+    iq = (opt.mode >> 2) & 3
+    if iq != 2 and not opt.lowpass_in:
+        return None
+    din = dm.design(opt, "in")
+    return conditioning_slack(data, opt.buf_size, din["taps"], din["bias_im"], dm.design(opt)["taps"],
+                              normalize=(iq == 3))
+
+
 def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: bool,
-            extra_abs: np.ndarray | None = None) -> Report:
+            extra_abs: np.ndarray | None = None, outlier_abs: np.ndarray | None = None) -> Report:
     """prefilter: use the wrap-aware (inexact-arithmetic) criterion, see inexact_path().
-    extra_abs: per-output absolute allowance on top of it (conditioning_slack)."""
+    extra_abs: per-output absolute allowance on top of it, for every output (-q2).
+    outlier_abs: the same kind of allowance, consulted only for outputs beyond the loose bound."""
     gpu = np.asarray(gpu, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert gpu.shape == ref.shape, (gpu.shape, ref.shape)
@@ -144,9 +166,17 @@ def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: b
             d = gpu[i] - ref[i]
             if np.min(np.abs(combos - d)) <= loose * scale[i] + (float(extra_abs[i]) if extra_abs is not None else 0.0):
                 n_wrap += 1
+            elif outlier_abs is not None and abs(d) <= loose * scale[i] + float(outlier_abs[i]):
+                n_wrap += 1     # ill-conditioned output, counted with the wrap outliers
             else:
                 still_bad.append(int(i))
-    n_loose = int(np.count_nonzero(over_tight & ~over_loose))
+    in_band = over_tight & ~over_loose
+    if outlier_abs is not None:
+        # an output the model calls ill-conditioned (its allowance alone exceeds the tight bound)
+        # is not held to the tight bound
+        oa = np.asarray(outlier_abs, dtype=np.float64)
+        in_band &= ~((oa > tight * scale) & (diff <= tight * scale + oa))
+    n_loose = int(np.count_nonzero(in_band))
     allowed_loose = max(2, int(np.ceil(1e-5 * n)))
     n_bad = len(still_bad) + max(0, n_loose - allowed_loose)
     return Report(n, float(diff.max()), float(rel.max()), n_loose, n_wrap, n_bad, still_bad[:8])

@@ -6,7 +6,7 @@ import pytest
 
 import demodulator_amd as dm
 import oracle
-from parity import compare, inexact_path, q2_slack
+from parity import compare, inexact_path, q2_slack, stage_slack
 
 pytestmark = pytest.mark.gpu
 
@@ -285,7 +285,8 @@ def test_random_option_sets_and_lengths(orc):
         assert got.size == want.size
         if not np.all(np.isfinite(want)):
             continue            # the reference itself overflows on this design (huge taps): nothing to pin
-        rep = compare(got, want, design["taps"], inexact_path(opt.lowpass_in, opt.mode), q2_slack(dm, opt, data))
+        rep = compare(got, want, design["taps"], inexact_path(opt.lowpass_in, opt.mode), q2_slack(dm, opt, data),
+                      stage_slack(dm, opt, data))
         assert rep.ok, f"{opt} n_bytes={n_bytes}: {rep}"
         n_cases += 1
     assert n_cases >= min(30, rounds // 2)
