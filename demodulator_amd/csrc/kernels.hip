@@ -299,7 +299,13 @@ __device__ __forceinline__ float stencil0(const float *h, const float *v) {
 // by less than the reference's own FMA / non-FMA builds differ).
 // Samples past a chunk end are 0.0f in the reference, i.e. 128 in this domain.
 template <int TIN, int COND, bool RAGGED>
-constexpr bool fold_unpack() { return TIN > 0 && COND == kShiftOrigin; }  // every build: results must not depend on which one ran
+constexpr bool fold_unpack() {
+#ifdef DEMOD_NO_FOLD   // experiment: what the folded unpack bias buys
+    return false;
+#else
+    return TIN > 0 && COND == kShiftOrigin;
+#endif
+}  // every build: results must not depend on which one ran
 
 // One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
 // `valid` = usable bytes of this lane's 16 (16 unless RAGGED); `ex` supplies the
