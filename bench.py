@@ -15,17 +15,26 @@ Workloads (BASELINE.json / SURVEY.md section 8d):
     c4      2^31 samples per GPU of one sharded stream (configs[3]: 2^34 at 8 GPUs)
     c5      32 channels x 2^24 samples per GPU, batched (configs[4]: 256 channels at 8 GPUs)
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run;
-the global stream is cut into N contiguous shards.  By default the cut points
-are NOT chunk boundaries (every shard starts 96 KiB into a 256 KiB chunk), so
-each rank needs the 64 look-ahead bytes that follow its shard: they are
-exchanged every step with RCCL send/recv (torch.distributed P2P, backend
-"nccl" = RCCL over xGMI) inside the timed region.  --aligned cuts at chunk
-boundaries instead (no exchange is needed then, and none is made).  Barriers,
-the max over ranks and one vote run over a gloo control group; the vote follows
-one untimed exchange under a watchdog: if RCCL point-to-point does not come up
-on the node, the run falls back to chunk-aligned cuts and says so in
-config.sharding instead of hanging.
+For N > 1 there is one process per GPU: either the driver launches them with
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment), or -- invoked plainly as `python bench.py --gpus N` -- this
+script starts N child processes itself, BEFORE anything touches the GPU, waits
+for them and returns the worst exit code (rank 0 prints the line).  The global
+stream is cut into N contiguous shards.  By default the cut points are NOT
+chunk boundaries (every shard starts 96 KiB into a 256 KiB chunk), so each rank
+needs the 64 look-ahead bytes that follow its shard: they are exchanged every
+step with RCCL send/recv (torch.distributed P2P, backend "nccl" = RCCL over
+xGMI) inside the timed region.  --aligned cuts at chunk boundaries instead (no
+exchange is needed then, and none is made).  Barriers, the max over ranks and
+the votes run over a gloo control group.
+
+The RCCL point-to-point path is health-checked first in throw-away child
+processes (demodulator_amd/sharding.py::run_probe_child): a probe that hangs is
+killed from outside and this process never holds a stuck communicator.  If the
+probe does not pass on every rank, the run still measures and prints the line
+for chunk-aligned cuts (no exchange), but says `"halo_exchange": "failed"` at
+top level and EXITS NON-ZERO: a line produced that way has not exercised the
+halo mechanism and must not read as a pass.
 
 Before the W warm-up steps every rank spins the device up for --prewarm-ms
 (default 300 ms) of the same work, as part of set-up: a fresh process runs its
@@ -105,34 +114,8 @@ def cpu_baseline(sample_log2: int, flags: dict, seed: int, fetch=None) -> dict:
     return res
 
 
-def _exchange_works(torch, dist, fn, timeout_s: float = 90.0) -> bool:
-    """One untimed halo exchange under a watchdog, then a vote over the (gloo)
-    control group: True only if it completed on every rank.  The point-to-point
-    path over RCCL is the one part of this benchmark that cannot be rehearsed on a
-    one-GPU box; if it does not come up on the node, the run falls back to
-    chunk-aligned cuts (which need no exchange) instead of hanging."""
-    import threading
-
-    state = {"ok": False}
-
-    def probe():
-        try:
-            fn()
-            torch.cuda.synchronize()
-            state["ok"] = True
-        except Exception as e:  # noqa: BLE001
-            state["err"] = repr(e)
-
-    t = threading.Thread(target=probe, daemon=True)
-    t.start()
-    t.join(timeout_s)
-    flag = torch.tensor([1 if (state["ok"] and not t.is_alive()) else 0], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(flag.item())
-
-
 def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int, world: int,
-                 aligned: bool, seg_rows: int, prewarm_ms: float = 300.0, data_group=None, place: bool = True):
+                 aligned: bool, seg_rows: int, prewarm_ms: float = 300.0, data_group=None):
     wl = WORKLOADS[name]
     n_bytes = 2 << wl["log2_samples"]  # per GPU
     opt = dm.Options(**wl["flags"])
@@ -148,22 +131,17 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     phase = 0 if (aligned or world == 1) else PHASE_BYTES
     shards = plan_shards(n_bytes * world, world, B, phase_bytes=phase)
     me = shards[rank]
-    right = shards[rank + 1] if rank + 1 < world else None
+    right = shards[me.halo_src] if me.needs_halo else None
     assert me.length == n_bytes
     iq = torch.empty(n_bytes, dtype=torch.uint8, device=dev)
     s16 = wl.get("out") == "s16"
     if s16:
         d.set_output_format("s16", 1.0 / (3.14159265 * float(abs(d.taps("out")[0]).sum())))
-    # The output buffer is placed inside a slightly larger allocation: input byte i is read
-    # while output byte i is written, so how the two buffers sit relative to each other in
-    # the HBM channel/bank interleave matters on some devices of the pool (tools/skew_probe.py:
-    # up to 7 % between the best and the worst offset on one box, nothing on another).  Set-up
-    # below tries a few offsets, untimed, and keeps the best.
-    odt = torch.int16 if s16 else torch.float32
-    esz = 2 if s16 else 4
-    slack = 48 << 20
-    big = torch.empty(n_bytes // 4 + slack // esz, dtype=odt, device=dev)
-    out = big[: n_bytes // 4]
+    # The output buffer sits where the allocator puts it -- what a user of the library gets.
+    # (How the input and output buffers lie relative to each other in the HBM channel/bank
+    # interleave moves the kernel time by up to 7 % on some devices of the pool and not at
+    # all on others: tools/skew_probe.py, profiles/r1_buffer_placement.txt.)
+    out = torch.empty(n_bytes // 4, dtype=torch.int16 if s16 else torch.float32, device=dev)
     d.synth_fill(iq, me.start, wl["seed"])  # this rank's bytes of the global stream
     halo = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device=dev)
 
@@ -179,23 +157,6 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
                 exchange_halo(me, right, mine, theirs)
                 halo.copy_(theirs)
 
-    def first_exchange():
-        if data_group is not None:
-            # every rank takes part in one collective first, so that the communicator exists
-            # before the point-to-point messages (which not every rank need send or receive)
-            dist.all_reduce(torch.zeros(1, device=dev), group=data_group)
-        exchange()
-
-    fell_back = False
-    if world > 1 and phase and not _exchange_works(torch, dist, first_exchange):
-        # no exchange on this node: cut at chunk boundaries instead (reference-aligned shards)
-        fell_back = True
-        phase = 0
-        shards = plan_shards(n_bytes * world, world, B, phase_bytes=0)
-        me = shards[rank]
-        right = shards[rank + 1] if rank + 1 < world else None
-        d.synth_fill(iq, me.start, wl["seed"])
-
     def step():
         exchange()
         d.process(iq, out, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
@@ -210,20 +171,6 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
         d.process(iq, out, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
                   end_of_stream=me.end_of_stream)
         torch.cuda.synchronize()
-    out_skew = 0
-    if place:
-        d.kernel_ms()
-        best = None
-        for skew in (0, 32 << 10, 128 << 10, 1 << 20, 16 << 20, 34 << 20):
-            cand = big[skew // esz: skew // esz + n_bytes // 4]
-            for _ in range(4):
-                d.process(iq, cand, chunk_offset=me.chunk_offset, halo=halo if me.needs_halo else None,
-                          end_of_stream=me.end_of_stream)
-            torch.cuda.synchronize()
-            ms, _n = d.kernel_ms()
-            if best is None or ms < best[0] * 0.995:   # move only for a gain beyond the noise
-                best = (ms, skew, cand)
-        out_skew, out = best[1], best[2]
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -242,14 +189,54 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     dispatches = max(1, d.last_call_launches)
     checksum = float(out[1000003:: max(1, out.numel() // 4099)].double().abs().sum().item())
     d.close()
-    del iq, out, big
+    del iq, out
     torch.cuda.empty_cache()
     return dict(dt=dt, kernel_ms=kms, launches=launches, n_bytes=n_bytes, opt=opt, checksum=checksum,
-                phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches,
-                fell_back=fell_back, out_skew=out_skew)
+                phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches)
 
 
-def main() -> None:
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as
+    child processes (the parent makes no GPU call, before or after), wait for all of
+    them and return the worst exit code.  Rank 0 prints the JSON line on the
+    inherited stdout.  When a rank dies the others get a grace period, then are
+    killed by PID (they would wait in a barrier for ever)."""
+    import subprocess
+
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    worst = 0
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.time() + 60.0
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = p.wait()
+        worst = max(worst, abs(rc) if rc else 0)
+    return worst
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -261,9 +248,12 @@ def main() -> None:
                     help="untimed device spin-up before the warm-up steps (set-up, see run_workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
-    ap.add_argument("--no-placement", action="store_true",
-                    help="keep the output buffer where the allocator put it (no offset trial at set-up)")
+    ap.add_argument("--probe-timeout", type=float, default=120.0,
+                    help="seconds the point-to-point health check may take before it is killed")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)   # before torch is imported: the parent never touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -273,9 +263,8 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the demodulation path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -283,20 +272,49 @@ def main() -> None:
     # (ranks share devices, the 64-byte halos travel through host memory); never for reported numbers
     backend = os.environ.get("DEMOD_BENCH_BACKEND", "nccl")
     data_group = None
+    halo_exchange = "none (1 GPU)" if world == 1 else "none (chunk-aligned cuts)"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # control plane (barriers, the max over ranks, the fallback vote) on gloo;
+        # control plane (barriers, the max over ranks, the votes) on gloo;
         # the data path -- the 64-byte look-ahead of every cut -- on RCCL
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        if backend == "nccl" and not args.aligned:
-            try:
-                data_group = dist.new_group(backend="nccl")
-            except Exception:  # noqa: BLE001
+
+        def all_agree(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        if not args.aligned:
+            # 1. health check in throw-away processes with a rendezvous of their own: a hang
+            #    is killed from outside, this process makes no RCCL call before it has passed
+            from demodulator_amd.sharding import run_probe_child
+
+            port = [_free_port() if rank == 0 else 0]
+            dist.broadcast_object_list(port, src=0)
+            ok = run_probe_child(backend, rank, world, local_rank, port[0], args.probe_timeout,
+                                 force_fail=os.environ.get("DEMOD_BENCH_FORCE_PROBE_FAIL") == "1")
+            ok = all_agree(ok)
+            # 2. the communicator of this process; every rank votes on the outcome, so that all
+            #    of them cut the stream the same way
+            if ok and backend == "nccl":
+                try:
+                    data_group = dist.new_group(backend="nccl")
+                    dist.all_reduce(torch.zeros(1, device="cuda"), group=data_group)  # communicator exists
+                    torch.cuda.synchronize()                                          # before any send/recv
+                    mine = True
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write(f"[rank {rank}] RCCL group: {e!r}\n")
+                    mine = False
+                ok = all_agree(mine)
+            if ok:
+                halo_exchange = "rccl send/recv" if backend == "nccl" else f"{backend} send/recv (rehearsal)"
+            else:
+                halo_exchange = "failed"
                 data_group = None
-                args.aligned = True
+                args.aligned = True   # still measure: chunk-aligned cuts need no exchange
 
     r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
-                     args.segment_rows, args.prewarm_ms, data_group, not args.no_placement)
+                     args.segment_rows, args.prewarm_ms, data_group)
     dt = r["dt"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -319,15 +337,16 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (counter-based splitmix64 uint8 IQ, generated on device)",
+        "halo_exchange": halo_exchange,
         "config": {
             "workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}",
             "samples_per_gpu": samples_per_gpu,
             "chunk_bytes": r["chunk"],
-            "output_offset_bytes": r["out_skew"],
             "sharding": ("1 GPU" if world == 1 else
                          f"{world} contiguous shards, " +
-                         ("chunk-aligned cuts, no exchange" + (" (the RCCL look-ahead exchange did not come up on "
-                                                                 "this node: fell back)" if r["fell_back"] else "")
+                         ("chunk-aligned cuts, no exchange" +
+                          (" (the point-to-point health check FAILED on this node: the halo path was not "
+                           "exercised, exit code 3)" if halo_exchange == "failed" else "")
                           if not r["phase"] else
                           f"cuts {r['phase']} B into a chunk, 64-byte look-ahead via "
                           f"{'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} send/recv per step")),
@@ -374,7 +393,7 @@ def main() -> None:
                     continue
                 bps = 3 if WORKLOADS[name].get("out") == "s16" else ALGO_BYTES_PER_SAMPLE
                 x = run_workload(dm, torch, dist, name, max(5, args.steps), 2, 0, 1, True, args.segment_rows,
-                                 args.prewarm_ms, None, not args.no_placement)
+                                 args.prewarm_ms, None)
                 sp = x["n_bytes"] // 2
                 steps = max(5, args.steps)
                 a = bps * sp / (x["kernel_ms"] * 1e-3)  # per step (1 dispatch at 2^30 samples)
@@ -401,11 +420,10 @@ def main() -> None:
 
     if world > 1:
         dist.barrier()
-        if r["fell_back"]:
-            sys.stdout.flush()
-            os._exit(0)  # a stuck RCCL probe must not keep the process from ending
         dist.destroy_process_group()
+    # a line measured without the halo mechanism it was asked to exercise is not a pass
+    return 3 if halo_exchange == "failed" else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -55,7 +55,9 @@ class Options:
 
 def design(options: Options, which: str = "out") -> dict:
     """Host-only filter design (no GPU needed): SOS rows, stencil taps, the
-    imaginary-lane bias and the per-chunk head length for an option set."""
+    imaginary-lane bias and the per-chunk head length for an option set.
+    which: "out" (-l), "in" (-L, or the -q2 highpass when alone), "pre" (the -q2
+    highpass when it runs in front of -L)."""
     lib = _native.load()
     p = options.c_struct()
     rows = np.zeros((16, 6), dtype=np.float32)
@@ -63,7 +65,7 @@ def design(options: Options, which: str = "out") -> dict:
     bias = C.c_float(0)
     n_taps = C.c_int(0)
     head = C.c_int(0)
-    n = lib.demod_design_query(C.byref(p), 1 if which == "in" else 0, rows.ctypes.data, 16,
+    n = lib.demod_design_query(C.byref(p), {"out": 0, "in": 1, "pre": 2}[which], rows.ctypes.data, 16,
                                taps.ctypes.data, 8, C.byref(bias), C.byref(n_taps), C.byref(head))
     if n < 0:
         raise DemodError(f"demod_design_query failed ({n}): {lib.demod_last_error(None).decode()}")

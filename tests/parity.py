@@ -1,26 +1,53 @@
-"""Parity criteria for the HIP path against the reference.
+"""The parity criterion of the HIP path against the reference -- ONE
+criterion, used by every test (golden, seeded, full-size, CLI, random sweep).
 
-Stated tolerances (float32 outputs, full chunks; the tail follows the build's
-deterministic policy, Appendix B.1):
+Domain: full chunks (the tail follows the build's deterministic policy, Appendix B.1).
 
-* no input filter (-L absent) and the default shiftOrigin unpack, where every
-  discriminator argument is an exact small integer: |gpu - ref| <= 4e-6 absolute on EVERY output for
-  the default stencil (sum |h| = 2.306); scaled by sum|h| / 2.306 for designs
-  with larger taps.  The reference's own FMA vs non-FMA builds differ by up to
-  1.43e-6 here.  The sign of +-pi results must match exactly, which this bound
-  enforces (a wrong sign is an error of 2*pi*|h|).
-* with -L, with the -q2 highpassDc conditioning (a complex filter like -L's), or
-  with the -q3 normalizeInput unpack (inputs byte*2/255-1 are not exact, so the reference's separately rounded products and this path's FMAs
-  can land on opposite sides of the negative real axis):
-  |gpu - ref| <= 2e-5 * max(1, |ref|) for >= 99.999 % of the outputs
-  and <= 1e-4 * max(1, |ref|) for the rest (reference self-difference: max
-  3.7e-5, p99.999 4.3e-6), scaled likewise, EXCEPT wrap outliers: when the
-  discriminator argument lies within rounding of the negative real axis, +pi and
-  -pi are equally valid roundings, and an output may differ by 2*pi*(+-h[j]) or
-  a sum of those; such outputs are counted and reported, not failed.
-* -q2 (and, for outliers only, every path with a complex stage in the random sweep): a
-  condition-aware allowance, conditioning_slack() below -- where the filtered sample nearly
-  vanishes the discriminator's argument is rounding noise in the reference itself.
+(1) EXACT path -- no complex stage and the default shiftOrigin unpack, where every
+    discriminator argument is an exact small integer:
+        |gpu - ref| <= 4e-6 * g   on EVERY output
+    (the reference's own FMA and non-FMA builds differ by up to 1.43e-6 here).  The sign of
+    +-pi results must match exactly, which this bound enforces (a wrong sign is an error of
+    2*pi*|h|).
+
+(2) INEXACT path -- with -L, with -q2 (highpassDc, a complex stage like -L's) or with -q3
+    (normalizeInput: samples byte*2/255-1 are rounded values):
+        |gpu - ref| <= 2e-5 * g * max(1, |ref|) + cond(n)   for >= 99.999 % of the outputs,
+        |gpu - ref| <= 1e-4 * g * max(1, |ref|) + cond(n)   for the rest,
+    except WRAP OUTLIERS: the difference is a combination of +-2*pi*h_out[j] (to within the
+    loose bound) AND the model below confirms that the discriminator argument of a
+    contributing output lies within rounding (2e-6 rad + the conditioning turns) of the
+    negative real axis, where +pi and -pi are equally valid roundings.  They are counted and
+    reported.  Where no model is available (the input bytes were not handed to compare) they
+    are capped at max(2, 1e-5 n) instead, so that a systematic sign error cannot pass.
+
+g:      1.0 for the BASELINE flag sets (C2: sum|h_out| = 2.306, C3 / target: 3.073); designs
+        with larger output taps scale the bounds by sum|h_out| / 3.073 (an error in one
+        discriminator value reaches the output multiplied by the taps).
+
+cond(n): CONDITIONING CLAUSE, zero unless a complex stage runs.  The discriminator value is the
+        ARGUMENT of z[2n] * conj(z[2n+1]); an absolute rounding error e in a filtered sample z
+        turns it by e / |z|.  The filtered samples are hundreds of units long almost
+        everywhere, but about one in 1e8 (lowpass taps; one in 1e6 with the -q2 highpass taps
+        (+3, -1), which cancel wherever x[k+1] = 3 x[k]) lands next to zero, and there the
+        reference's result is rounding noise: ITS OWN two legitimate builds (generic and
+        IS_NATIVE = FMA contraction) differ from each other by more
+        than the loose bound at exactly those outputs -- 3 outputs of the 5.4e8 of BASELINE
+        config 3 (chunks 2819, 4174, 5812 of the synthetic stream; 1.1e-4 .. 1.6e-4), and
+        3e-3 relative with -q2.  No other implementation can be closer to the reference than
+        it is to itself.  Model, in float64 from the input bytes:
+            z[k]   = sum_j h_in[j] x[k+j] + i*bias                (zeros past the chunk end)
+            A[k]   = sum_j a_in[j] (|xr[k+j]| + |xi[k+j]|) + a0     running error bound: the same
+                     recurrence with every coefficient replaced by its magnitude (abs_taps),
+                     i.e. the size of the intermediate results the reference rounds
+            e[k]   = COND_ULPS * 2^-24 * A[k]
+            cond(n) = sum_j |h_out[j]| * (min(pi, e/|z|) at 2(n+j) and at 2(n+j)+1)
+        COND_ULPS is pinned to evidence, not chosen: tests/test_oracle_golden.py::
+        test_reference_self_difference_pins_the_conditioning_clause measures the smallest
+        constant under which the reference's two builds agree with each other on the BASELINE
+        config-3 stream, on -q2 streams and on Chebyshev / 3-tap designs, and asserts that it
+        lies below COND_ULPS while WITHOUT the clause the reference fails against itself.
+        Head outputs of a chunk (partial sections) get no allowance.
 """
 from __future__ import annotations
 
@@ -29,7 +56,10 @@ from dataclasses import dataclass
 
 import numpy as np
 
-DEFAULT_GAIN = 1.760042 + 0.5457233
+BASELINE_GAIN = 2.3492503 + 0.72343695   # sum|h_out| of BASELINE config 3 / the target (the larger of the two)
+COND_ULPS = 1.0
+TIGHT, LOOSE, EXACT_ABS = 2e-5, 1e-4, 4e-6
+NEAR_AXIS = 2e-6                        # |pi - |angle|| (plus the conditioning turns) below which +pi and -pi are both valid roundings
 
 
 @dataclass
@@ -37,121 +67,167 @@ class Report:
     n: int
     max_abs: float
     max_rel: float
-    n_loose: int        # beyond the tight bound but within the loose one
-    n_wrap: int         # wrap outliers (with -L only)
-    n_bad: int
+    n_band: int         # beyond the tight bound, within the loose one
+    n_wrap: int         # wrap outliers
+    n_cond: int         # outputs that needed the conditioning clause to stay within the loose bound
+    n_beyond: int       # outputs beyond the loose bound that nothing explains
     first_bad: list
+    wraps_confirmed: bool = True   # every wrap outlier was confirmed by the model (else: capped)
+
+    @property
+    def n_bad(self) -> int:
+        """Violations of the criterion: unexplained outputs, plus what exceeds the 1e-5
+        fraction allowed between the bounds, plus unconfirmed wrap outliers beyond their cap.
+        Reports add up (a stream compared slab by slab is judged on its totals)."""
+        cap = max(2, int(np.ceil(1e-5 * self.n)))
+        return (self.n_beyond + max(0, self.n_band - cap)
+                + (0 if self.wraps_confirmed else max(0, self.n_wrap - cap)))
 
     @property
     def ok(self) -> bool:
         return self.n_bad == 0
 
+    @property
+    def n_tight(self) -> int:
+        return self.n - self.n_band - self.n_wrap - self.n_beyond
+
     def __str__(self) -> str:
-        return (f"n={self.n} max_abs={self.max_abs:.3e} max_rel={self.max_rel:.3e} "
-                f"loose={self.n_loose} wrap={self.n_wrap} bad={self.n_bad} first_bad={self.first_bad}")
+        return (f"n={self.n} within_tight={self.n_tight} in_band={self.n_band} wrap={self.n_wrap}"
+                f"{'' if self.wraps_confirmed else '(unconfirmed)'} "
+                f"needed_cond_clause={self.n_cond} beyond={self.n_beyond} violations={self.n_bad} "
+                f"max_abs={self.max_abs:.3e} max_rel={self.max_rel:.3e} first_bad={self.first_bad}")
+
+    def __add__(self, o: "Report") -> "Report":
+        return Report(self.n + o.n, max(self.max_abs, o.max_abs), max(self.max_rel, o.max_rel),
+                      self.n_band + o.n_band, self.n_wrap + o.n_wrap, self.n_cond + o.n_cond,
+                      self.n_beyond + o.n_beyond, (self.first_bad + o.first_bad)[:8],
+                      self.wraps_confirmed and o.wraps_confirmed)
 
 
 def inexact_path(lowpass_in: float, mode: int) -> bool:
     """True when the discriminator arguments are rounded values (-L, -q2, -q3):
-    selects the wrap-aware criterion."""
+    selects criterion (2)."""
     return lowpass_in != 0 or ((mode >> 2) & 3) in (2, 3)
 
 
-def conditioning_slack(data: np.ndarray, chunk_bytes: int, taps_in, bias_im: float, taps_out,
-                       ulps: float = 8.0, normalize: bool = False) -> np.ndarray:
-    """Extra absolute difference allowed per output where the reference's own result is
-    ill-conditioned: the discriminator is the ARGUMENT of z[2n] * conj(z[2n+1]), so an
-    absolute rounding error e in a filtered sample z moves it by e / |z|.  The -q2 highpass
-    taps are (+3, -1) to within 1e-4, so z nearly vanishes wherever x[k+1] = 3 x[k] (and the
-    imaginary lane's -2 cancels too); there the reference's FMA and non-FMA builds differ
-    from each other by 1e-3 and more (measured: 3.3e-3 on the fuzz case that motivated this),
-    and no other implementation can be closer to it than it is to itself.  Model, in
-    float64: z[k] = sum_j h[j] x[k+j] + i*bias (zeros past the chunk end), e[k] = `ulps`
-    float32 ulps of the magnitudes summed, slack[n] = sum_j |h_out[j]| * (e/|z| at 2(n+j)
-    and 2(n+j)+1), capped at pi per discriminator value."""
+def abs_taps(sos: np.ndarray) -> tuple[np.ndarray, float]:
+    """Running-error form of the sectioned recurrence (src/filter.c:212-259): the look-ahead
+    taps and the constant it collapses to when every coefficient is replaced by its magnitude
+    -- a bound on the size of the intermediate values the reference rounds.  Same recursion
+    as plan.cpp::derive_taps."""
+    sos = np.asarray(sos, dtype=np.float64)
+    S = sos.shape[0]
+    coef = np.zeros((S + 2, S + 3))
+    bias = np.zeros(S + 2)
+    for m in range(S - 1, -1, -1):
+        b0, b1 = abs(sos[m][0]), abs(sos[m][1])
+        coef[m] = b0 * coef[m + 1]
+        coef[m][1:] += b1 * coef[m + 2][:-1]
+        coef[m][0] += abs(sos[m][4])
+        coef[m][1] += abs(sos[m][5])
+        bias[m] = b0 * bias[m + 1] + b1 * bias[m + 2] + abs(sos[m][3]) + 1.0
+    nz = np.nonzero(coef[0])[0]
+    return coef[0][: (nz[-1] + 1 if nz.size else 1)].copy(), float(bias[0])
+
+
+@dataclass
+class Conditioning:
+    cond: np.ndarray       # cond(n) for COND_ULPS = 1, one per output
+    near_axis: np.ndarray  # bool per output: a contributing discriminator argument lies next to the negative real axis
+    head: int              # head outputs per chunk (no allowance there)
+
+
+def conditioning(dm, opt, data: np.ndarray) -> Conditioning | None:
+    """The model above for an option set (dm: the demodulator_amd module), None when no
+    complex stage runs and the unpack is exact (criterion (1))."""
+    iq = (opt.mode >> 2) & 3
+    if not inexact_path(opt.lowpass_in, opt.mode):
+        return None
+    dout = dm.design(opt)
+    g = np.abs(np.asarray(dout["taps"], dtype=np.float64))
     data = np.asarray(data, dtype=np.uint8)
     n = data.size & ~3
-    if normalize:
-        x = data[:n].astype(np.float64) * (2.0 / 255.0) - 1.0  # normalizeInput (-q3)
+    if iq == 3:
+        x = data[:n].astype(np.float64) * (2.0 / 255.0) - 1.0     # normalizeInput
+        xerr = 2.0 ** -24                                           # the samples themselves are rounded
     else:
-        x = ((data[:n].astype(np.int32) + 1) & 255) - 128      # shiftOrigin
-    h = np.asarray(taps_in, dtype=np.float64)
-    g = np.abs(np.asarray(taps_out, dtype=np.float64))
-    out = np.zeros(n // 4, dtype=np.float64)
+        x = (((data[:n].astype(np.int32) + 1) & 255) - 128).astype(np.float64)
+        xerr = 0.0
+    has_stage = iq == 2 or opt.lowpass_in != 0
+    if has_stage:
+        din = dm.design(opt, "in")
+        h = np.asarray(din["taps"], dtype=np.float64)
+        bias = float(din["bias_im"])
+        a, a0 = abs_taps(din["sos"])
+        if iq == 2 and opt.lowpass_in != 0:                         # highpassDc in front of -L: two stages
+            ap, ap0 = abs_taps(dm.design(opt, "pre")["sos"])
+            a0 = a0 + float(np.sum(a)) * ap0
+            a = np.convolve(ap, a)
+    else:
+        h, bias, a, a0 = np.ones(1), 0.0, np.zeros(1), 0.0
+    B = opt.buf_size
+    out_cond = np.zeros(n // 4)
+    out_axis = np.zeros(n // 4, dtype=bool)
+    pad = max(len(h), len(a)) + 1
     pos = 0
     while pos < n:
-        ln = min(chunk_bytes, n - pos)
-        xc = x[pos:pos + ln].astype(np.float64)
+        ln = min(B, n - pos)
+        xc = x[pos:pos + ln]
         k = ln // 2
-        xr = np.concatenate([xc[0::2], np.zeros(len(h))])
-        xi = np.concatenate([xc[1::2], np.zeros(len(h))])
+        xr = np.concatenate([xc[0::2], np.zeros(pad)])
+        xi = np.concatenate([xc[1::2], np.zeros(pad)])
         zr = sum(h[j] * xr[j:j + k] for j in range(len(h)))
-        zi = sum(h[j] * xi[j:j + k] for j in range(len(h))) + bias_im
-        mag = sum(abs(h[j]) * (np.abs(xr[j:j + k]) + np.abs(xi[j:j + k])) for j in range(len(h))) + abs(bias_im)
-        e = ulps * 2.0 ** -24 * mag
+        zi = sum(h[j] * xi[j:j + k] for j in range(len(h))) + bias
+        ar, ai = np.abs(xr), np.abs(xi)
+        A = sum(a[j] * (ar[j:j + k] + ai[j:j + k]) for j in range(len(a))) + a0
+        A = A + xerr * 2.0 ** 24 * sum(abs(h[j]) for j in range(len(h)))   # -q3: one rounding per sample
+        e = 2.0 ** -24 * A
         turn = np.minimum(np.pi, e / np.maximum(np.hypot(zr, zi), 1e-30))
-        dd = np.concatenate([turn[0::2] + turn[1::2], np.zeros(len(g))])
         m = ln // 4
-        out[pos // 4:pos // 4 + m] = sum(g[j] * dd[j:j + m] for j in range(len(g)))
+        dd = np.concatenate([turn[0:2 * m:2] + turn[1:2 * m:2], np.zeros(len(g))])
+        out_cond[pos // 4:pos // 4 + m] = sum(g[j] * dd[j:j + m] for j in range(len(g)))
+        # discriminator argument p = z[2n] * conj(z[2n+1]) next to the negative real axis?
+        pr = zr[0:2 * m:2] * zr[1:2 * m:2] + zi[0:2 * m:2] * zi[1:2 * m:2]
+        pj = zi[0:2 * m:2] * zr[1:2 * m:2] - zr[0:2 * m:2] * zi[1:2 * m:2]
+        ax = np.concatenate([(np.pi - np.abs(np.arctan2(pj, pr))) <= NEAR_AXIS + 4 * turn[0:2 * m:2] + 4 * turn[1:2 * m:2],
+                             np.zeros(len(g), dtype=bool)])
+        out_axis[pos // 4:pos // 4 + m] = np.logical_or.reduce([ax[j:j + m] for j in range(len(g)) if g[j] != 0])
+        H = int(dout["head_outputs"])
+        out_cond[pos // 4:pos // 4 + min(H, m)] = 0.0
         pos += ln
-    return out
+    return Conditioning(out_cond, out_axis, int(dout["head_outputs"]))
 
 
-def q2_slack(dm, opt, data) -> np.ndarray | None:
-    """conditioning_slack for an option set with -q2, None otherwise (dm: the demodulator_amd module)."""
-    if ((opt.mode >> 2) & 3) != 2:
-        return None
-    din = dm.design(opt, "in")
-    return conditioning_slack(data, opt.buf_size, din["taps"], din["bias_im"], dm.design(opt)["taps"])
+def gain_of(taps_out) -> float:
+    return max(1.0, float(np.sum(np.abs(taps_out))) / BASELINE_GAIN)
 
 
-def stage_slack(dm, opt, data) -> np.ndarray | None:
-    """conditioning_slack for any option set with a complex stage (-L and/or -q2), None
-    otherwise.  For -L it is used to adjudicate OUTLIERS only (compare(outlier_abs=...)): with
-    lowpass taps the filtered sample is hundreds of units long almost everywhere, but about one
-    output in 1e8 sits next to zero, and there this path's folded unpack bias (absolute error
-    of a few 1e-5 in the sample) can exceed the loose bound (seen once in 12000 fuzz cases:
-    1.4e-4 against an allowance of 1.6e-3 at that output)."""
-    iq = (opt.mode >> 2) & 3
-    if iq != 2 and not opt.lowpass_in:
-        return None
-    din = dm.design(opt, "in")
-    return conditioning_slack(data, opt.buf_size, din["taps"], din["bias_im"], dm.design(opt)["taps"],
-                              normalize=(iq == 3))
-
-
-def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: bool,
-            extra_abs: np.ndarray | None = None, outlier_abs: np.ndarray | None = None) -> Report:
-    """prefilter: use the wrap-aware (inexact-arithmetic) criterion, see inexact_path().
-    extra_abs: per-output absolute allowance on top of it, for every output (-q2).
-    outlier_abs: the same kind of allowance, consulted only for outputs beyond the loose bound."""
+def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, inexact: bool,
+            cond: Conditioning | None = None, cond_ulps: float = COND_ULPS) -> Report:
+    """inexact: criterion (2), see inexact_path().  cond: conditioning(dm, opt, data) for the
+    same bytes (None: no allowance -- the plain stated tolerance, wrap outliers capped)."""
     gpu = np.asarray(gpu, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert gpu.shape == ref.shape, (gpu.shape, ref.shape)
     n = ref.size
     if n == 0:
-        return Report(0, 0.0, 0.0, 0, 0, 0, [])
-    gain = max(1.0, float(np.sum(np.abs(taps_out))) / DEFAULT_GAIN)
-    diff = np.abs(gpu - ref)
-    scale = np.maximum(1.0, np.abs(ref))
-    if extra_abs is not None:
-        # judged on what exceeds the allowance
-        diff = np.maximum(0.0, diff - np.asarray(extra_abs, dtype=np.float64))
-    rel = diff / scale
+        return Report(0, 0.0, 0.0, 0, 0, 0, 0, [])
+    g = gain_of(taps_out)
     finite = np.isfinite(gpu)
-    if not prefilter:
-        bad = (diff > 4e-6 * gain) | ~finite
-        idx = np.nonzero(bad)[0]
-        return Report(n, float(diff.max()), float(rel.max()), 0, 0, int(idx.size), idx[:8].tolist())
+    diff = np.where(finite, np.abs(gpu - ref), np.inf)
+    scale = np.maximum(1.0, np.abs(ref))
+    rel = diff / scale
+    if not inexact:
+        idx = np.nonzero(diff > EXACT_ABS * g)[0]
+        return Report(n, float(diff.max()), float(rel.max()), 0, 0, 0, int(idx.size), idx[:8].tolist())
 
-    tight = 2e-5 * gain
-    loose = 1e-4 * gain
-    over_tight = rel > tight
-    over_loose = (rel > loose) | ~finite
-    # wrap outliers: difference explained by +-2*pi*h[j] combinations
+    allow = cond_ulps * cond.cond[:n] if cond is not None else np.zeros(n)
+    over_tight = diff > TIGHT * g * scale + allow
+    over_loose = diff > LOOSE * g * scale + allow
+    n_cond = int(np.count_nonzero((diff > LOOSE * g * scale) & ~over_loose))
     n_wrap = 0
-    idx_loose = np.nonzero(over_loose)[0]
     still_bad = []
+    idx_loose = np.nonzero(over_loose)[0]
     if idx_loose.size:
         h = [float(v) for v in taps_out if v != 0.0]
         combos = set()
@@ -160,23 +236,46 @@ def compare(gpu: np.ndarray, ref: np.ndarray, taps_out: np.ndarray, prefilter: b
                 combos.add(2 * np.pi * sum(s * v for s, v in zip(signs, h)))
         combos = np.array(sorted(combos))
         for i in idx_loose:
-            if not finite[i]:
-                still_bad.append(int(i))
-                continue
             d = gpu[i] - ref[i]
-            if np.min(np.abs(combos - d)) <= loose * scale[i] + (float(extra_abs[i]) if extra_abs is not None else 0.0):
+            explained = finite[i] and np.min(np.abs(combos - d)) <= LOOSE * g * scale[i] + allow[i]
+            if explained and (cond is None or cond.near_axis[i]):
                 n_wrap += 1
-            elif outlier_abs is not None and abs(d) <= loose * scale[i] + float(outlier_abs[i]):
-                n_wrap += 1     # ill-conditioned output, counted with the wrap outliers
             else:
                 still_bad.append(int(i))
-    in_band = over_tight & ~over_loose
-    if outlier_abs is not None:
-        # an output the model calls ill-conditioned (its allowance alone exceeds the tight bound)
-        # is not held to the tight bound
-        oa = np.asarray(outlier_abs, dtype=np.float64)
-        in_band &= ~((oa > tight * scale) & (diff <= tight * scale + oa))
-    n_loose = int(np.count_nonzero(in_band))
-    allowed_loose = max(2, int(np.ceil(1e-5 * n)))
-    n_bad = len(still_bad) + max(0, n_loose - allowed_loose)
-    return Report(n, float(diff.max()), float(rel.max()), n_loose, n_wrap, n_bad, still_bad[:8])
+    n_band = int(np.count_nonzero(over_tight & ~over_loose))
+    return Report(n, float(diff.max()), float(rel.max()), n_band, n_wrap, n_cond, len(still_bad), still_bad[:8],
+                  cond is not None)
+
+
+def compare_stream(dm, opt, got, want, data, *, use_cond: bool = True) -> Report:
+    """The criterion for an option set on a whole stream (or slab of whole chunks; a short
+    last chunk is fine).  The conditioning model is built only for the chunks that hold an
+    output beyond the tight bound -- everywhere else it could only loosen a bound that
+    already holds -- so this costs one numpy pass over the outputs."""
+    taps = dm.design(opt)["taps"]
+    inexact = inexact_path(opt.lowpass_in, opt.mode)
+    if not inexact or data is None or not use_cond:
+        return compare(got, want, taps, inexact, None)
+    got = np.asarray(got)
+    want = np.asarray(want)
+    n = want.size
+    g = gain_of(taps)
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    flagged = np.nonzero(~(d <= TIGHT * g * np.maximum(1.0, np.abs(want.astype(np.float64)))))[0]
+    cond = Conditioning(np.zeros(n), np.zeros(n, dtype=bool), 0)
+    B = opt.buf_size
+    Ld = B // 4
+    data = np.asarray(data, dtype=np.uint8)
+    for c in np.unique(flagged // Ld):
+        m = conditioning(dm, opt, data[c * B:(c + 1) * B])
+        k = m.cond.size
+        cond.cond[c * Ld:c * Ld + k] = m.cond
+        cond.near_axis[c * Ld:c * Ld + k] = m.near_axis
+    return compare(got, want, taps, True, cond)
+
+
+def check(dm, opt, got, want, data=None, *, name: str = "", use_cond: bool = True) -> Report:
+    """Assert the criterion for an option set (conditioning model from the input bytes when given)."""
+    rep = compare_stream(dm, opt, got, want, data, use_cond=use_cond)
+    assert rep.ok, f"{name or opt}: {rep}"
+    return rep

@@ -10,7 +10,7 @@ import pytest
 
 import demodulator_amd as dm
 import oracle
-from parity import compare, q2_slack
+from parity import check, compare
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def test_cli_readme_dsd_pipe(manifest, golden):
     want = golden(c["file"])
     assert got.size == want.size == data.size // 4      # byte-exact output length
     opt = dm.Options(**c["flags"])
-    assert compare(got, want, dm.design(opt)["taps"], False).ok
+    check(dm, opt, got, want, data)
 
 
 def test_cli_readme_multimon_pipe_files(tmp_path, manifest, golden):
@@ -51,7 +51,7 @@ def test_cli_readme_multimon_pipe_files(tmp_path, manifest, golden):
     want = oracle.restatement().process(oracle.Flags(**opt.__dict__), np.frombuffer(raw, np.uint8))
     assert got.size == want.size == len(raw) // 4
     assert np.array_equal(want[: data.size // 4].view(np.uint32), golden(c["file"]).view(np.uint32))
-    assert compare(got, want, dm.design(opt)["taps"], True).ok
+    check(dm, opt, got, want, np.frombuffer(raw, np.uint8))
 
 
 def test_cli_default_chunk_many_chunks():
@@ -61,7 +61,7 @@ def test_cli_default_chunk_many_chunks():
     got = np.frombuffer(out, dtype=np.float32)
     want = oracle.restatement().process(oracle.Flags(**opt.__dict__), data)
     assert got.size == want.size
-    assert compare(got, want, dm.design(opt)["taps"], False).ok
+    check(dm, opt, got, want, data)
 
 
 def test_cli_highpass_dc_conditioning(manifest, golden):
@@ -74,14 +74,14 @@ def test_cli_highpass_dc_conditioning(manifest, golden):
     got = np.frombuffer(out, dtype=np.float32)
     want = golden(c["file"])
     assert got.size == want.size
-    assert compare(got, want, dm.design(opt)["taps"], True, q2_slack(dm, opt, data)).ok
+    check(dm, opt, got, want, data)
     # ... and in front of -L
     c = manifest["streams"]["q2_L_b32768"]
     opt = dm.Options(**c["flags"])
     data = oracle.synth_bytes(c["seed"], 0, c["n_chunks"] * opt.buf_size)
     out = _run([DEMOD, "-i", "-", "-o", "-", "-q", "2", "-L", "12500", "-l", "6500", "-b", "-3"], data.tobytes())
     got = np.frombuffer(out, dtype=np.float32)
-    assert compare(got, golden(c["file"]), dm.design(opt)["taps"], True, q2_slack(dm, opt, data)).ok
+    check(dm, opt, got, golden(c["file"]), data)
 
 
 def test_cli_int16_output_env():
@@ -120,7 +120,7 @@ def test_reference_host_on_this_backend(manifest, golden):
         want = golden(c["file"])
         assert got.size == want.size
         opt = dm.Options(**c["flags"])
-        assert compare(got, want, dm.design(opt)["taps"], key == "multimon").ok, key
+        check(dm, opt, got, want, data, name=key)
 
 
 def test_cli_seamless_env(manifest, golden):

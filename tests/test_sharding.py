@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from demodulator_amd import HALO_BYTES
-from demodulator_amd.sharding import plan_shards, exchange_halo
+from demodulator_amd.sharding import plan_shards, exchange_halo, run_probe_child
 
 
 def test_plan_chunk_aligned_needs_no_exchange():
@@ -44,6 +44,29 @@ def test_plan_tiny_chunks_and_degenerate():
     assert all(s.start % 64 == 0 and not s.needs_halo for s in sh) and sh[-1].stop == 6400
     sh = plan_shards(1024, 4, 262144)          # fewer rows than ranks: empty shards are legal
     assert sum(s.length for s in sh) == 1024 and not any(s.needs_halo and s.length == 0 for s in sh)
+    assert not any(s.sends_halo or s.needs_halo for s in sh)      # one row: nothing follows it
+    assert [s.end_of_stream for s in sh] == [s.stop == 1024 for s in sh]
+
+
+def test_plan_empty_shards_take_no_part_in_the_exchange():
+    """Every send has exactly one matching receive, also when shards are empty: the
+    look-ahead of a shard comes from the next NON-EMPTY shard."""
+    B = 262144
+    for total, world in ((3 * 1024, 4), (2 * 1024 + 40, 5), (5 * 1024, 8), (7 * 1024 + 4, 3)):
+        sh = plan_shards(total, world, B, align=1024)
+        assert sum(s.length for s in sh) == total
+        for s in sh:
+            if s.length == 0:
+                assert not s.needs_halo and not s.sends_halo
+            if s.needs_halo:
+                src = sh[s.halo_src]
+                assert src.length > 0 and src.start == s.stop and src.halo_dst == s.rank
+            if s.sends_halo:
+                dst = sh[s.halo_dst]
+                assert dst.needs_halo and dst.halo_src == s.rank
+        last = max(s.rank for s in sh if s.length)
+        assert sh[last].end_of_stream and not sh[last].needs_halo
+        assert sum(s.needs_halo for s in sh) == sum(s.sends_halo for s in sh)
     with pytest.raises(ValueError):
         plan_shards(1 << 20, 2, 16384, phase_bytes=100)
 
@@ -61,7 +84,7 @@ def _worker(rank, world, port, total, B, phase, seed, q):
     try:
         shards = plan_shards(total, world, B, phase_bytes=phase, align=1024)
         me = shards[rank]
-        right = shards[rank + 1] if rank + 1 < world else None
+        right = shards[me.halo_src] if me.needs_halo else None
         iq = torch.from_numpy(oracle.synth_bytes(seed, me.start, me.length))
         halo = torch.zeros(HALO_BYTES, dtype=torch.uint8)
         for _ in range(3):                      # a few steps, as bench.py does
@@ -93,3 +116,33 @@ def test_halo_exchange_over_gloo(world, phase):
             assert np.array_equal(halo[: want.size], want), rank
         else:
             assert not halo.any()                # untouched: no message was sent to this rank
+
+
+def _probe_worker(rank, world, port, q, force_fail):
+    q.put((rank, run_probe_child("gloo", rank, world, rank, port, 60.0, force_fail=force_fail)))
+
+
+@pytest.mark.parametrize("force_fail", [False, True])
+def test_exchange_probe_in_child_processes(force_fail):
+    """The health check bench.py runs before trusting the point-to-point path: one
+    throw-away process per rank with a rendezvous of its own; a failing probe is
+    reported (False), never raised into the caller."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q, force_fail)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert got == {0: not force_fail, 1: not force_fail}
+
+
+def test_exchange_probe_that_hangs_is_killed():
+    """A probe whose peer never shows up is killed after its timeout (by PID) and reads as failed."""
+    import time
+    t0 = time.time()
+    assert run_probe_child("gloo", 0, 2, 0, _free_port(), 8.0) is False
+    assert time.time() - t0 < 60
