@@ -27,7 +27,7 @@ EXPORTS = (
     "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_output_format",
     "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
     "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
-    "demod_enable_timing",
+    "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound",
 )
 
 
@@ -105,6 +105,8 @@ def load() -> C.CDLL:
         "demod_kernel_ms": (C.c_double, [vp, C.POINTER(i32)]),
         "demod_last_call_launches": (i32, [vp]),
         "demod_enable_timing": (None, [vp, i32]),
+        "demod_last_error_code": (i32, [vp]),
+        "demod_design_magnitude_bound": (C.c_double, [C.POINTER(Params)]),
     }
     for name in EXPORTS:
         fn = getattr(lib, name)  # AttributeError here = the library does not match the header

@@ -80,9 +80,13 @@ struct demod_ctx {
 
     float *sink = nullptr;  // 1 KiB store sink for chunk-head lanes of the streaming kernel
 
-    // scratch for the whole-chunk literal path (chunks < 1 KiB)
+    // scratch for the whole-chunk literal path (chunks < 1 KiB): ONE buffer, thread t
+    // always uses work + t * stride, so launches on different streams (the host path's
+    // slots) are ordered through tiny_done: each waits for the one before it
     float *tiny_work = nullptr;
     uint64_t tiny_stride = 0;
+    hipEvent_t tiny_done = nullptr;
+    bool tiny_pending = false;
 
     // host path staging: two slots, each pinned in/out + device in/out + stream
     struct Slot {
@@ -96,6 +100,7 @@ struct demod_ctx {
     int collect_slot = 0;  // oldest slot not yet collected
     int in_flight = 0;
 
+    int err_code = DEMOD_OK;  // code of the failure `err` describes (demod_last_error_code)
     bool fail(int code, const char *what, hipError_t e = hipSuccess) {
         char buf[384];
         if (e != hipSuccess)
@@ -103,7 +108,7 @@ struct demod_ctx {
         else
             snprintf(buf, sizeof buf, "%s", what);
         err = buf;
-        (void) code;
+        err_code = code;
         return false;
     }
 };
@@ -141,6 +146,8 @@ const char *demod_last_error(const demod_ctx *ctx) {
     copy = g_create_error;
     return copy.c_str();
 }
+
+int demod_last_error_code(const demod_ctx *ctx) { return ctx ? ctx->err_code : DEMOD_E_INVAL; }
 
 static int create_fail(int code, const std::string &msg) {
     std::lock_guard<std::mutex> g(g_err_mutex);
@@ -214,6 +221,7 @@ void demod_destroy(demod_ctx *ctx) {
         (void) hipEventDestroy(p.second);
     }
     if (ctx->tiny_work) (void) hipFree(ctx->tiny_work);
+    if (ctx->tiny_done) (void) hipEventDestroy(ctx->tiny_done);
     if (ctx->sink) (void) hipFree(ctx->sink);
     if (ctx->aux) (void) hipStreamDestroy(ctx->aux);
     if (ctx->fork_ev) (void) hipEventDestroy(ctx->fork_ev);
@@ -329,12 +337,19 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
                     uint32_t tail_bytes, void *d_out, hipStream_t stream) {
     const Plan &pl = ctx->plan;
     const uint64_t stride = 6 * chunk_bytes + 3 * (4 * kMaxSections + 8);
+    if (!ctx->tiny_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tiny_done, hipEventDisableTiming));
     if (!ctx->tiny_work || ctx->tiny_stride < stride) {
-        if (ctx->tiny_work) HIP_TRY(ctx, hipFree(ctx->tiny_work));
+        if (ctx->tiny_work) {
+            HIP_TRY(ctx, hipDeviceSynchronize());  // an earlier launch may still be using it
+            HIP_TRY(ctx, hipFree(ctx->tiny_work));
+        }
         ctx->tiny_work = nullptr;
+        ctx->tiny_pending = false;
         HIP_TRY(ctx, hipMalloc((void **) &ctx->tiny_work, (size_t) kTinyThreads * stride * sizeof(float)));
         ctx->tiny_stride = stride;
     }
+    // the scratch is shared: wait for the previous literal launch, whatever stream it ran on
+    if (ctx->tiny_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tiny_done, 0));
     TinyLaunch t{};
     t.in = d_in;
     t.out = d_out;
@@ -353,6 +368,8 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
         ctx->fail(DEMOD_E_HIP, "demod_tiny launch", hipGetLastError());
         return DEMOD_E_HIP;
     }
+    HIP_TRY(ctx, hipEventRecord(ctx->tiny_done, stream));
+    ctx->tiny_pending = true;
     return DEMOD_OK;
 }
 
@@ -812,6 +829,14 @@ int demod_design_query(const demod_params *p, int which, float *rows6, int max_r
     if (n_taps) *n_taps = sn.taps;
     if (head_outputs) *head_outputs = plan.head_outputs;
     return st.sections;
+}
+
+double demod_design_magnitude_bound(const demod_params *p) {
+    if (!p) return (double) create_fail(DEMOD_E_INVAL, "null argument");
+    Plan plan;
+    std::string err;
+    if (!build_plan(options_from_params(*p), plan, err)) return (double) create_fail(DEMOD_E_INVAL, err);
+    return plan.magnitude_bound;
 }
 
 int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed,

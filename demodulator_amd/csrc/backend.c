@@ -7,7 +7,12 @@
  * out under the mutex and posts `empty`.  Unlike the reference consumer this one
  * reads bufSize and exitFlag exactly once per hand-off, under the mutex, so the
  * last chunk is never lost or duplicated, and a final
- * partial chunk of r bytes yields r/4 outputs.
+ * partial chunk of r bytes yields r/4 outputs.  The chunk size B is read the same
+ * way at start-up: the producer overwrites bufSize with the byte count of its
+ * first read as soon as it wins the mutex (src/main.c:88), so what is found there
+ * is either B or -- when the whole input is shorter than one chunk -- that count,
+ * which is rounded up to the next power of two: a short only-chunk is filtered
+ * as a chunk of its own length whatever B is, so the result is the same.
  *
  * GPU work is pipelined two deep (demod_stream_submit / _collect): while chunk
  * i is uploaded, demodulated and downloaded, chunk i-1 is written to outFile
@@ -65,16 +70,25 @@ void *processMatrix(void *ctx) {
     demod_consumer_args *args = ctx;
     demod_params p;
     demod_ctx *dm = NULL;
-    const size_t chunk = args->bufSize; /* B, before the producer starts overwriting it */
+    size_t chunk; /* B */
     int pending = 0;
     /* DEMOD_SEAMLESS=1: filter the stream as one chunk (demod_set_seamless); not reference behaviour */
     const char *env_seamless = getenv("DEMOD_SEAMLESS");
-    const int seamless = env_seamless && env_seamless[0] == '1' && chunk >= 1024;
+    int seamless;
     unsigned char *held = NULL; /* seamless: the hand-off waiting for its look-ahead */
     size_t held_n = 0;
     uint64_t stream_pos = 0;
     unsigned char halo[DEMOD_HALO_BYTES];
 
+    pthread_mutex_lock(&args->mutex);
+    chunk = args->bufSize;
+    pthread_mutex_unlock(&args->mutex);
+    {
+        size_t b = 4;
+        while (b < chunk) b <<= 1;
+        chunk = b;
+    }
+    seamless = env_seamless && env_seamless[0] == '1' && chunk >= 1024;
     demod_default_params(&p);
     p.sample_rate = (double) args->sampleRate;
     p.lowpass_in = (double) args->lowpassIn;

@@ -89,7 +89,8 @@ __device__ __forceinline__ uint32_t bit_select(uint32_t a, uint32_t b, uint32_t 
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0xCA);
 }
 
-// atan2(y, x) for finite arguments with IEEE signed-zero behaviour:
+// atan2(y, x) for FINITE arguments (guaranteed by plan.cpp::plan_magnitude_bound: a design
+// that could overflow is refused at context creation) with IEEE signed-zero behaviour:
 //   atan2(+-0, x >= +0) = +-0, atan2(+-0, x <= -0) = +-pi  (SURVEY.md Appendix A.2).
 // Octant reduction to q = min/max in [0, 1], odd minimax polynomial q*P(q^2)
 // (8 coefficients, |error| < 7e-8 before rounding), one v_rcp_f32.  The octant
@@ -140,7 +141,11 @@ __device__ __forceinline__ float discriminate(float a, float b, float c, float d
 __device__ __forceinline__ float discriminate_literal(float a, float b, float c, float d) {
     const float zr = a * c + b * d;
     const float zj = -a * d + b * c;
-    return fast_atan2(zj, zr);
+    const float r = fast_atan2(zj, zr);
+    // src/matrix.c:174 maps a NaN result to 0.  build_plan proves every value of the path
+    // finite from the design (plan_magnitude_bound), so this never fires; the literal
+    // kernels keep the reference's statement, the streaming kernel relies on the proof.
+    return r != r ? 0.f : r;
 }
 
 // Four bytes -> (byte + 1) & 255 each, all four at once (SWAR): adding 1 to the

@@ -156,6 +156,53 @@ void derive_taps(Stage &st) {
     st.bias_im = (float) bias[0];
 }
 
+namespace {
+
+// Magnitude bound of one sectioned stage: every intermediate value of the recurrence
+// (src/filter.c:221-230, :242-258) is a partial sum of the terms below, so with inputs
+// bounded by `in` and the cells it starts from bounded by `init`,
+//   M(m) = |b0| M(m+1) + |b1| M(m+2) + |a1| in + |a2| in + |a0| + 1,   M(S) = M(S+1) = init
+// bounds what section m leaves in a cell and everything it computes on the way.
+double stage_bound(const Stage &st, double in, double init) {
+    const int S = st.sections;
+    double m1 = init, m2 = init, worst = init;
+    for (int m = S - 1; m >= 0; --m) {
+        const double b0 = std::fabs((double) st.sos[m][0]), b1 = std::fabs((double) st.sos[m][1]);
+        const double v = b0 * m1 + b1 * m2 + (std::fabs((double) st.sos[m][4]) + std::fabs((double) st.sos[m][5])) * in +
+                         std::fabs((double) st.sos[m][3]) + 1.0;
+        m2 = m1;
+        m1 = v;
+        worst = std::max(worst, v);
+    }
+    return worst;
+}
+
+}  // namespace
+
+// Largest magnitude any float of the path can take for this plan (samples, filtered
+// samples, the overflow cells fed by the stage's own output, discriminator arguments,
+// outputs), from the design alone.  The reference maps a NaN discriminator value to 0
+// (src/matrix.c:174); NaN can only come out of non-finite arithmetic, and every
+// intermediate of the reference's recurrences is bounded by this figure, so for an accepted
+// plan neither the reference nor this path ever leaves the finite floats and the rule is
+// vacuous.  Designs beyond the limit are refused (the reference prints inf / NaN->0 garbage).
+double plan_magnitude_bound(const Plan &pl) {
+    const double x = pl.conditioning == kNormalize ? 1.0 : 128.0;
+    double z = x;
+    if (pl.pre.sections) z = stage_bound(pl.pre, z, 0.0);
+    double worst = z;
+    if (pl.in.sections) {
+        const double cell = stage_bound(pl.in, z, 0.0);            // cells of the stage proper
+        const double over = stage_bound(pl.in, pl.in_separate ? 0.0 : cell, 0.0);  // overflow cells read the stage's own output
+        z = std::max(cell, over);
+        worst = std::max(worst, z);
+    }
+    worst = std::max(worst, 2.0 * z * z);                           // zr = a c + b d, zj = -a d + b c
+    const double pi = 3.14159274;
+    worst = std::max(worst, stage_bound(pl.out, pi, pl.in.sections ? z : 0.0));   // output cells start from the overflow cells
+    return worst;
+}
+
 bool build_plan(const Options &o, Plan &plan, std::string &err) {
     char msg[256];
     const unsigned demod_mode = (o.mode >> 4) & 3;
@@ -251,6 +298,17 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
                 }
     if (plan.stencil_in.taps > kMaxTaps || plan.out.taps > kMaxTaps) {
         err = "stencil longer than supported";
+        return false;
+    }
+
+    // Finite arithmetic is proven here, once, instead of being tested per output (see
+    // plan_magnitude_bound): 1e30 leaves eight decades to FLT_MAX for the products' rounding.
+    plan.magnitude_bound = plan_magnitude_bound(plan);
+    if (!(plan.magnitude_bound < 1e30)) {
+        snprintf(msg, sizeof msg,
+                 "this filter design can overflow float32 (magnitude bound %.3g): the reference's own output is "
+                 "inf / NaN->0 for it (src/matrix.c:174) and it is refused", plan.magnitude_bound);
+        err = msg;
         return false;
     }
 

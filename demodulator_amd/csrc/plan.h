@@ -62,7 +62,12 @@ struct Plan {
     Stage out;   // real output filter (-l)
     int head_outputs = 0;  // H: outputs per chunk that the closed form does not cover
     int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row that leave their store to the head kernel
+    double magnitude_bound = 0;  // plan_magnitude_bound(): every float of the path stays below this
 };
+
+// Bound on the magnitude of every intermediate and result of the path for a plan (finite
+// arithmetic is proven from the design; build_plan refuses plans beyond 1e30).
+double plan_magnitude_bound(const Plan &pl);
 
 // Pre-warped bilinear Butterworth / Chebyshev-I design -> float SOS rows
 // (what processFilterOption leaves in sosf, /root/reference/src/matrix.c:25-80).

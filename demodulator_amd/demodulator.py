@@ -70,7 +70,7 @@ def design(options: Options, which: str = "out") -> dict:
     if n < 0:
         raise DemodError(f"demod_design_query failed ({n}): {lib.demod_last_error(None).decode()}")
     return {"sos": rows[:n].copy(), "taps": taps[:n_taps.value].copy(), "bias_im": float(bias.value),
-            "head_outputs": int(head.value)}
+            "head_outputs": int(head.value), "magnitude_bound": float(lib.demod_design_magnitude_bound(C.byref(p)))}
 
 
 class Demodulator:
@@ -112,6 +112,7 @@ class Demodulator:
 
     def _check(self, rc: int, what: str) -> None:
         if rc != 0:
+            assert self._lib.demod_last_error_code(self._ctx) == rc   # the message belongs to this failure
             raise DemodError(f"{what} failed ({rc}): {self._lib.demod_last_error(self._ctx).decode()}")
 
     # -- introspection ----------------------------------------------------------
@@ -207,6 +208,37 @@ class Demodulator:
         rc = self._lib.demod_process_host(self._ctx, data.ctypes.data, n, out.ctypes.data, C.byref(span))
         self._check(rc, "demod_process_host")
         return out
+
+    # -- pipelined host path (what the backend adapter drives) -------------------
+    @property
+    def stream_capacity(self) -> int:
+        return int(self._lib.demod_stream_capacity())
+
+    def stream_submit(self, data: np.ndarray, *, chunk_offset: int = 0, halo: np.ndarray | None = None,
+                      end_of_stream: bool = True) -> None:
+        """demod_stream_submit: copy `data` into a pinned staging slot and enqueue upload, hot
+        path and download; returns at once.  At most stream_depth pieces may be uncollected."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        hp = None
+        if halo is not None:
+            halo = np.ascontiguousarray(halo, dtype=np.uint8)
+            if halo.size < _native.HALO_BYTES:
+                halo = np.concatenate([halo, np.zeros(_native.HALO_BYTES - halo.size, np.uint8)])
+            hp = halo.ctypes.data
+        span = Span(chunk_offset, hp, 1 if end_of_stream else 0, 0)
+        self._check(self._lib.demod_stream_submit(self._ctx, data.ctypes.data, data.size & ~3, C.byref(span)),
+                    "demod_stream_submit")
+
+    def stream_collect(self) -> np.ndarray | None:
+        """demod_stream_collect: results of the OLDEST submitted piece (a copy), None when nothing is pending."""
+        out = C.c_void_p()
+        n = C.c_uint64(0)
+        self._check(self._lib.demod_stream_collect(self._ctx, C.byref(out), C.byref(n)), "demod_stream_collect")
+        if not n.value:
+            return None
+        dt = self.output_dtype
+        buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(out.value)
+        return np.frombuffer(buf, dtype=dt).copy()
 
     # -- helpers ----------------------------------------------------------------
     def synth_fill(self, dst, first_byte: int, seed: int) -> None:

@@ -101,8 +101,10 @@ int demod_abi_version(void);
 int demod_create(const demod_params *p, int device, demod_ctx **out);
 void demod_destroy(demod_ctx *ctx);
 
-/* Last error text of a context (or of demod_create when ctx == NULL). */
+/* Last error text of a context (or of demod_create when ctx == NULL), and the
+ * DEMOD_E_* code of the failure it describes. */
 const char *demod_last_error(const demod_ctx *ctx);
+int demod_last_error_code(const demod_ctx *ctx);
 
 /* HOT PATH.  Demodulate n_bytes of uint8 IQ resident in device memory at d_in
  * into n_bytes/4 float32 (or int16, see demod_set_output_format) at d_out, asynchronously on `stream` (a hipStream_t
@@ -161,6 +163,15 @@ int demod_get_head_outputs(const demod_ctx *ctx);
  * negative error code with the text in demod_last_error(NULL). */
 int demod_design_query(const demod_params *p, int which, float *rows6, int max_rows, float *taps,
                        int max_taps, float *bias_im, int *n_taps, int *head_outputs);
+
+/* Largest magnitude any float of the path can take for an option set (samples,
+ * filtered samples, overflow cells, discriminator arguments, outputs), proven
+ * from the design alone (host only).  The reference turns a NaN discriminator
+ * value into 0 (src/matrix.c:174); NaN needs non-finite arithmetic, and context
+ * creation refuses every design whose bound reaches 1e30 -- for an accepted
+ * design the rule never fires, here or in the reference.  Returns the bound, or
+ * a negative error code (as a double) with the text in demod_last_error(NULL). */
+double demod_design_magnitude_bound(const demod_params *p);
 
 /* Seamless mode (not reference behaviour; off by default): the whole stream is
  * filtered as ONE chunk, so the look-ahead stencils run across what would be

@@ -136,3 +136,31 @@ def test_cli_seamless_env(manifest, golden):
     want = oracle.restatement().process(oracle.Flags(**{**opt.__dict__, "buf_size": data.size}), data)
     assert got.size == want.size
     assert compare(got, want, dm.design(opt)["taps"], True).ok
+
+
+def test_cli_input_shorter_than_one_chunk():
+    """The whole input is one short read: the producer overwrites args->bufSize with the
+    byte count before the backend thread has looked at it (src/main.c:88).  The backend
+    reads the field under the mutex and rounds it up to a power of two; a short only-chunk
+    is filtered as a chunk of its own length either way."""
+    for n, flags, kw in ((1000, [], {}), (4, [], {}), (70000, ["-L", "12500", "-l", "6500"], dict(lowpass_in=12500.0, lowpass_out=6500.0)),
+                         (262140, [], {})):
+        opt = dm.Options(**kw)
+        data = oracle.synth_bytes(0x518 + n, 0, n)
+        for _ in range(3):                                   # the race has two outcomes; both must be right
+            got = np.frombuffer(_run([DEMOD, "-i", "-", "-o", "-"] + flags, data.tobytes()), dtype=np.float32)
+            want = oracle.restatement().process(oracle.Flags(**opt.__dict__), data)
+            assert got.size == want.size == n // 4
+            check(dm, opt, got, want, data, name=f"short input {n}")
+
+
+def test_cli_tiny_chunks_many_handoffs():
+    """-b -12 (64-byte chunks): every hand-off is one chunk through the literal kernel, two in
+    flight on different streams sharing one scratch buffer."""
+    for flags, kw, b, B in (([], {}, "-12", 64), (["-L", "12500", "-l", "6500"], dict(lowpass_in=12500.0, lowpass_out=6500.0), "-13", 32)):
+        opt = dm.Options(buf_size=B, **kw)
+        data = oracle.synth_bytes(0x519, 0, 6000 * B + 20)
+        got = np.frombuffer(_run([DEMOD, "-i", "-", "-o", "-", "-b", b] + flags, data.tobytes()), dtype=np.float32)
+        want = oracle.restatement().process(oracle.Flags(**opt.__dict__), data)
+        assert got.size == want.size
+        check(dm, opt, got, want, data, name=f"cli -b {b}")

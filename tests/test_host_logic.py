@@ -160,3 +160,40 @@ def test_hand_counted_waits_cover_every_asm_load():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()
     assert b" 0 violations" in r.stdout
+
+
+def test_every_accepted_design_is_proven_finite():
+    """The reference maps a NaN discriminator value to 0 (/root/reference/src/matrix.c:174).
+    NaN needs non-finite arithmetic; build_plan bounds every intermediate of the reference's
+    recurrences from the design's coefficients (plan_magnitude_bound) and refuses what could
+    reach 1e30, and designs whose coefficients are themselves non-finite.  So: whenever the
+    oracle's output is non-finite the design is refused, every accepted design's outputs are
+    finite and below the proven bound -- the NaN rule never fires, here or in the reference."""
+    import oracle
+    orc = oracle.restatement()
+    rng = np.random.default_rng(3)
+    accepted = refused = 0
+    for it in range(240):
+        wide = it % 2 == 0          # half the cases far outside sensible audio designs
+        opt = dm.Options(sample_rate=float(10 ** rng.uniform(3, 8)) if wide else float(rng.choice([96000., 125000., 192000.])),
+                         lowpass_in=(float(10 ** rng.uniform(0, 6)) if wide else 12500.0) if rng.random() < .5 else 0.0,
+                         lowpass_out=float(10 ** rng.uniform(0, 6)) if wide else float(rng.choice([6500., 12500.])),
+                         in_degree=0, out_degree=int(rng.integers(1, 17)),
+                         mode=0x10 | int(rng.integers(0, 4)) | int(rng.choice([0, 0, 8, 12])),
+                         epsilon=float(10 ** rng.uniform(-4, 1.5)) if wide else 0.3, buf_size=4096)
+        data = rng.integers(0, 256, 2 * opt.buf_size, dtype=np.uint8)
+        data[:1024] = rng.choice([0, 255, 127, 128], 1024)      # extremes as well
+        try:
+            want = orc.process(oracle.Flags(**opt.__dict__), data)
+        except ValueError:
+            continue
+        try:
+            bound = dm.design(opt)["magnitude_bound"]
+        except dm.DemodError as e:
+            refused += 1
+            assert "non-finite" in str(e) or "overflow" in str(e) or "-q2 together with -L" in str(e), e
+            continue
+        accepted += 1
+        assert np.all(np.isfinite(want)), opt
+        assert float(np.abs(want).max()) <= bound < 1e30, (opt, np.abs(want).max(), bound)
+    assert accepted >= 100 and refused >= 10
