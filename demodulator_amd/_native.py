@@ -27,7 +27,7 @@ EXPORTS = (
     "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_output_format",
     "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
     "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
-    "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound",
+    "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_set_head_mode",
 )
 
 
@@ -106,12 +106,19 @@ def load() -> C.CDLL:
         "demod_last_call_launches": (i32, [vp]),
         "demod_enable_timing": (None, [vp, i32]),
         "demod_last_error_code": (i32, [vp]),
+        "demod_set_head_mode": (i32, [vp, i32]),
         "demod_design_magnitude_bound": (C.c_double, [C.POINTER(Params)]),
     }
+    experiment = bool(os.environ.get("DEMOD_HIP_LIBRARY"))
     for name in EXPORTS:
-        fn = getattr(lib, name)  # AttributeError here = the library does not match the header
+        try:
+            fn = getattr(lib, name)  # AttributeError here = the library does not match the header
+        except AttributeError:
+            if experiment:           # an older build selected on purpose for an A/B run (tools/)
+                continue
+            raise
         fn.restype, fn.argtypes = sig[name]
-    if lib.demod_abi_version() != ABI_VERSION:
+    if lib.demod_abi_version() != ABI_VERSION and not experiment:
         raise DemodError("libdemod_hip.so ABI version mismatch")
     _lib = lib
     return lib

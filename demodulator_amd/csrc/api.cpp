@@ -25,6 +25,9 @@ std::string g_create_error;
 constexpr uint64_t kStageBytes = 32ull << 20;  // host path: input bytes per staged piece
 constexpr uint32_t kTinyThreads = 8192;
 constexpr uint32_t kPieceRows = 1u << 21;       // rows per demod_rows launch (2 GiB of input)
+// chunk heads inside the streaming kernel for chunks of at least this many rows (below, the
+// demod_heads kernel is cheaper), see heads_are_fused()
+constexpr uint64_t kFusedMinRows = 128;
 
 // Host-side staging copy (pageable <-> pinned): one thread moves ~10 GB/s, a PCIe Gen5
 // x16 link twice that in each direction, so large pieces are split over a few threads.
@@ -62,10 +65,8 @@ struct demod_ctx {
     int device = 0;
     std::string err;
 
-    hipStream_t aux = nullptr;  // chunk-head kernel runs here, beside the streaming kernel
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    bool heads_inline = false;
     bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
+    int head_mode = -1;     // demod_set_head_mode: -1 automatic, 0 demod_heads kernel, 1 inside the streaming kernel
     uint32_t seg_rows = 0;  // 0 = automatic
     uint32_t piece_rows = kPieceRows;  // rows per demod_rows dispatch
     bool out_s16 = false;              // results leave as int16 (demod_set_output_format)
@@ -77,8 +78,6 @@ struct demod_ctx {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
-
-    float *sink = nullptr;  // 1 KiB store sink for chunk-head lanes of the streaming kernel
 
     // scratch for the whole-chunk literal path (chunks < 1 KiB): ONE buffer, thread t
     // always uses work + t * stride, so launches on different streams (the host path's
@@ -179,22 +178,11 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
         return create_fail(DEMOD_E_INVAL, "device index out of range");
     }
     ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc((void **) &ctx->sink, kRowBytes)) != hipSuccess) {
+    if ((e = hipSetDevice(device)) != hipSuccess) {
         std::string msg = std::string("HIP setup failed: ") + hipGetErrorString(e);
         demod_destroy(ctx);
         return create_fail(DEMOD_E_HIP, msg);
     }
-    // The chunk-head kernel is independent of the streaming kernel (disjoint
-    // outputs) and can run beside it on the auxiliary stream, but measured on
-    // MI355X the overlap slows the streaming kernel by more (3-4 %) than the head
-    // kernel costs alone (~45 us per 32768 chunks), so it runs in line, first.
-    // DEMOD_HEADS_FORK=1 restores the forked form.
-    const char *fork = getenv("DEMOD_HEADS_FORK");
-    ctx->heads_inline = !(fork && fork[0] == '1');
     *out = ctx;
     return DEMOD_OK;
 }
@@ -222,10 +210,6 @@ void demod_destroy(demod_ctx *ctx) {
     }
     if (ctx->tiny_work) (void) hipFree(ctx->tiny_work);
     if (ctx->tiny_done) (void) hipEventDestroy(ctx->tiny_done);
-    if (ctx->sink) (void) hipFree(ctx->sink);
-    if (ctx->aux) (void) hipStreamDestroy(ctx->aux);
-    if (ctx->fork_ev) (void) hipEventDestroy(ctx->fork_ev);
-    if (ctx->join_ev) (void) hipEventDestroy(ctx->join_ev);
     delete ctx;
 }
 
@@ -259,6 +243,16 @@ int demod_output_bytes(const demod_ctx *ctx) { return ctx ? (int) ctx->out_bytes
 int demod_set_seamless(demod_ctx *ctx, int on) {
     if (!ctx) return DEMOD_E_INVAL;
     ctx->seamless = on != 0;
+    return DEMOD_OK;
+}
+
+int demod_set_head_mode(demod_ctx *ctx, int mode) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (mode < -1 || mode > 1) {
+        ctx->fail(DEMOD_E_INVAL, "head mode must be -1 (automatic), 0 (demod_heads kernel) or 1 (inside the streaming kernel)");
+        return DEMOD_E_INVAL;
+    }
+    ctx->head_mode = mode;
     return DEMOD_OK;
 }
 
@@ -307,7 +301,28 @@ double demod_kernel_ms(demod_ctx *ctx, int *launches) {
 // the hot path on device-resident data
 // ---------------------------------------------------------------------------
 
-static void fill_stencils(const Plan &pl, RowLaunch &r) {
+// Where the chunk heads are replayed.  The streaming kernel can do it itself (chunk_head:
+// one head per wavefront, one output per lane) when both stages have at most 4 sections and
+// highpassDc does not run in front of -L; whether it should is a matter of chunk size:
+// a head costs that wavefront about a third of a 4-row segment's arithmetic (~270 VALU
+// instructions with a quarter of the lanes busy), against ONE THREAD of the demod_heads kernel
+// (64 heads per wavefront, but a launch of its own).  Measured on MI355X (tools/chunk_sweep.py,
+// tools/head_mode_probe.py, profiles/r2_head_modes.txt): level from 128 KiB chunks up (one
+// kernel per dispatch, the default chunk size included), the separate kernel ahead below
+// that (64 KiB: 0.743 against 0.731 of peak, 16 KiB: 0.730 against 0.672, 1 KiB: 0.37
+// against 0.27).
+static bool heads_are_fused(const demod_ctx *ctx) {
+    const Plan &pl = ctx->plan;
+    if (pl.head_quads == 0) return true;
+    const bool can = pl.in.sections <= kFusedHeadSections && pl.out.sections <= kFusedHeadSections && pl.pre.sections == 0;
+    if (!can || ctx->head_mode == 0) return false;
+    if (ctx->head_mode == 1) return true;
+    const uint64_t rows_per_chunk = ctx->seamless ? (1ull << 31) : pl.chunk_bytes / kRowBytes;
+    return rows_per_chunk >= kFusedMinRows;
+}
+
+static void fill_stencils(const demod_ctx *ctx, RowLaunch &r) {
+    const Plan &pl = ctx->plan;
     for (int j = 0; j < kMaxTaps; ++j) {
         r.hin[j] = pl.stencil_in.h[j];
         r.hout[j] = pl.out.h[j];
@@ -320,6 +335,18 @@ static void fill_stencils(const Plan &pl, RowLaunch &r) {
         r.fold_im = (float) ((double) pl.stencil_in.bias_im - 128.0 * sum);
     }
     r.scale = (float) (2. / 255.);
+    // the chunk head is replayed inside the streaming kernel when both stages fit its
+    // lane-parallel form; otherwise (more than 4 sections, highpassDc in front of -L)
+    // demod_heads runs behind the streaming kernel and overwrites the head outputs
+    r.head_quads = (uint32_t) pl.head_quads;
+    r.fused_heads = heads_are_fused(ctx) ? 1u : 0u;
+    r.sec_in = pl.in.sections;
+    r.sec_out = pl.out.sections;
+    r.in_separate = pl.in_separate;
+    if (r.fused_heads) {
+        memcpy(r.sos_in, pl.in.sos, sizeof r.sos_in);
+        memcpy(r.sos_out, pl.out.sos, sizeof r.sos_out);
+    }
 }
 
 static void fill_sections(const Plan &pl, int &sec_in, int &sec_out, float (*sos_in)[6],
@@ -449,38 +476,11 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     uint32_t seg_log2 = log2u(ctx->seg_rows ? std::min(ctx->seg_rows, max_segment_rows()) : max_segment_rows());
     seg_log2 = std::min(seg_log2, rpc_log2);
 
-    // ---- chunk heads (literal replay), beside the streaming kernel --------
+    // chunk heads that start inside the buffer
     const uint64_t first_head = offset == 0 ? 0 : B - offset;
     uint32_t n_heads = 0;
     if (first_head < row_bytes) n_heads = (uint32_t) ((row_bytes - first_head + B - 1) / B);
-    hipStream_t head_stream = stream;
-    const bool forked = n_heads && pl.head_quads && !ctx->heads_inline;
-    if (n_heads && pl.head_quads) {
-        HeadLaunch h{};
-        h.in = d_in + first_head;
-        h.out = d_out + first_head / 4 * ob;
-        h.out_s16 = ctx->out_s16;
-        h.out_scale = ctx->out_scale;
-        h.chunk_bytes = B;
-        h.n_heads = n_heads;
-        h.head_outputs = 4u * (uint32_t) pl.head_quads;
-        const uint64_t last_len = row_bytes - (first_head + (uint64_t) (n_heads - 1) * B);
-        // a last chunk that continues past the buffer is a full chunk for the
-        // head window; only a stream end makes it short
-        h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
-        fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale, h.sec_pre, h.sos_pre);
-        h.in_separate = pl.in_separate;
-        if (forked) {
-            HIP_TRY(ctx, hipEventRecord(ctx->fork_ev, stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->fork_ev, 0));
-            head_stream = ctx->aux;
-        }
-        if (launch_heads(h, pl.conditioning, head_stream)) {
-            ctx->fail(DEMOD_E_HIP, "demod_heads launch", hipGetLastError());
-            return DEMOD_E_HIP;
-        }
-        if (forked) HIP_TRY(ctx, hipEventRecord(ctx->join_ev, ctx->aux));
-    }
+    uint64_t heads_from = 0;  // demod_heads replays the heads that start at or behind this byte of the buffer
 
     // ---- the fused streaming kernel ---------------------------------------
     if (row_bytes) {
@@ -488,12 +488,10 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         r.in = d_in;
         r.out = d_out;
         r.halo = (!eos && end_in_chunk != 0) ? halo : nullptr;
-        r.sink = ctx->sink;
         r.phase_rows = (uint32_t) (offset / kRowBytes);
         r.rpc_log2 = rpc_log2;
         r.seg_log2 = seg_log2;
-        r.head_quads = (uint32_t) pl.head_quads;
-        fill_stencils(pl, r);
+        fill_stencils(ctx, r);
         r.out_s16 = ctx->out_s16;
         r.out_scale = ctx->out_scale;
 
@@ -572,8 +570,33 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             HIP_TRY(ctx, hipEventRecord(ev.second, stream));
             ctx->timed.push_back(ev);
         }
+        // the streaming kernel replays the heads of the chunks whose first row its fast build
+        // computes; the bounds-checked build (ragged stream end) leaves its chunks' heads out
+        if (r.fused_heads) heads_from = (uint64_t) split * kRowBytes;
     }
-    if (forked) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->join_ev, 0));
+
+    // ---- chunk heads the streaming kernel did not replay (literal, one thread per chunk) ----
+    if (n_heads && pl.head_quads && first_head + (uint64_t) (n_heads - 1) * B >= heads_from) {
+        const uint32_t skip = heads_from > first_head ? (uint32_t) ((heads_from - first_head + B - 1) / B) : 0u;
+        HeadLaunch h{};
+        h.in = d_in + first_head + (uint64_t) skip * B;
+        h.out = d_out + (first_head + (uint64_t) skip * B) / 4 * ob;
+        h.out_s16 = ctx->out_s16;
+        h.out_scale = ctx->out_scale;
+        h.chunk_bytes = B;
+        h.n_heads = n_heads - skip;
+        h.head_outputs = 4u * (uint32_t) pl.head_quads;
+        const uint64_t last_len = row_bytes - (first_head + (uint64_t) (n_heads - 1) * B);
+        // a last chunk that continues past the buffer is a full chunk for the
+        // head window; only a stream end makes it short
+        h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
+        fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale, h.sec_pre, h.sos_pre);
+        h.in_separate = pl.in_separate;
+        if (launch_heads(h, pl.conditioning, stream)) {
+            ctx->fail(DEMOD_E_HIP, "demod_heads launch", hipGetLastError());
+            return DEMOD_E_HIP;
+        }
+    }
 
     if (tiny_tail) {
         const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4 * ob, stream);

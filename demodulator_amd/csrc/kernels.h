@@ -13,19 +13,25 @@ constexpr uint32_t kRowOutputs = 256;  // float32 results per row: 64 lanes x 4
 
 // Largest segment (rows per wavefront) the streaming kernel was built for.
 uint32_t max_segment_rows();
+// Sections per stage the streaming kernel's own chunk-head replay handles.
+constexpr int kFusedHeadSections = 4;
 
 // Main streaming kernel: rows [0, n_rows) of a device buffer.
 struct RowLaunch {
     const uint8_t *in;
     void *out;             // float32, or int16 when out_s16
     const uint8_t *halo;   // DEMOD_HALO_BYTES that follow the buffer in the stream (device), or null
-    float *sink;           // 1 KiB of device scratch that swallows the stores of chunk-head lanes
     uint32_t n_rows;       // rows this launch computes; the last one may be ragged
     uint32_t rows_readable; // rows that exist at `in` (>= n_rows): a launch may look ahead into the row after its last
     uint32_t phase_rows;   // chunk-local row index of buffer row 0
     uint32_t rpc_log2;     // log2(rows per chunk)
     uint32_t seg_log2;     // log2(rows per wavefront segment), <= rpc_log2
-    uint32_t head_quads;   // lanes of a chunk's row 0 whose outputs belong to the head kernel
+    uint32_t head_quads;   // lanes of a chunk's row 0 whose outputs are chunk-head outputs (ceil(H / 4))
+    // chunk head replayed by the wavefront that owns the chunk's row 0 (kernels.hip chunk_head); 0: left to demod_heads
+    uint32_t fused_heads;
+    int32_t sec_in, sec_out;  // sections of the complex stage (0 = none) and of the output stage
+    int32_t in_separate;      // Plan::in_separate
+    float sos_in[4][6], sos_out[4][6];
     uint32_t ragged_bytes; // valid bytes of the last row (multiple of 4, < 1024), 0 = full
     float hin[kMaxTaps];
     float bias_im;

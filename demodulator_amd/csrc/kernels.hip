@@ -11,9 +11,13 @@
 //              travel through a per-wavefront exchange line in LDS (no
 //              barriers).  16-byte loads and stores, 4 B of HBM traffic per IQ
 //              sample.
-// demod_heads  literal replay of the reference's sectioned recurrences for the
-//              first few outputs of every chunk (partial sections, overflow
-//              pollution).
+//              The wavefront that owns a chunk's first row also replays the
+//              reference's sectioned recurrences for the first few outputs of
+//              the chunk (partial sections, overflow pollution; SURVEY.md
+//              Appendix A.4), one output per lane (chunk_head).
+// demod_heads  the same replay, one thread per chunk, for what chunk_head does
+//              not cover: more than 4 sections, -q2 in front of -L, and the
+//              chunks of a bounds-checked (ragged) launch.
 // demod_tiny   literal whole-chunk path for chunks shorter than one row.
 //
 // Reference semantics restated here (never copied):
@@ -26,6 +30,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -36,16 +41,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef DEMOD_LOAD_POLICY
 #define DEMOD_LOAD_POLICY " nt"   // cache policy suffix of the streaming loads: every byte is read once
-#endif
 #ifndef DEMOD_WAVES_PER_BLOCK
 #define DEMOD_WAVES_PER_BLOCK 8
 #endif
 constexpr int kWavesPerBlock = DEMOD_WAVES_PER_BLOCK;  // independent wavefronts per workgroup of demod_rows
-#ifndef DEMOD_EXACT_WAITS
-#define DEMOD_EXACT_WAITS 1
-#endif
 // Workgroups are handed to the 8 XCDs round-robin.  With 8, the workgroups of a group of
 // eight take interleaved segments (XCD x streams segments x, x+8, x+16, ... of the group's
 // window) instead of eight contiguous 32 KiB pieces: +2-4 % on every box tried
@@ -305,12 +305,8 @@ __device__ __forceinline__ float stencil0(const float *h, const float *v) {
 // Samples past a chunk end are 0.0f in the reference, i.e. 128 in this domain.
 template <int TIN, int COND, bool RAGGED>
 constexpr bool fold_unpack() {
-#ifdef DEMOD_NO_FOLD   // experiment: what the folded unpack bias buys
-    return false;
-#else
     return TIN > 0 && COND == kShiftOrigin;
-#endif
-}  // every build: results must not depend on which one ran
+}
 
 // One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
 // `valid` = usable bytes of this lane's 16 (16 unless RAGGED); `ex` supplies the
@@ -428,11 +424,7 @@ __device__ __forceinline__ uint4 load_row16(const uint8_t *row_base, uint32_t la
 __device__ __forceinline__ void store_out16(float *dst, const float (&y)[4]) {
     f32x4 v;
     v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
-#ifdef DEMOD_NO_NT
-    *reinterpret_cast<f32x4 *>(dst) = v;
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
-#endif
 }
 
 // int16 output (DEMOD_OUT_S16): one signed-normalised conversion per pair,
@@ -474,6 +466,112 @@ __device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint
 }
 
 // ---------------------------------------------------------------------------
+// chunk head inside the streaming kernel: literal replay, one output per lane
+// ---------------------------------------------------------------------------
+// The first H = max(2 So - 1, 4 Si - 2) outputs of a chunk are not interior: cells near
+// the chunk start see only some of the sections, and with a complex stage its last
+// iterations write past its output into the cells the output stage starts from (SURVEY.md
+// Appendix A.4).  They are reproduced by executing the reference's own operation sequence
+// (src/filter.c:221-230, :242-258; same association, -ffp-contract=off).  That sequence is
+// sequential in the reference, but cell n after section m,
+//     P(n, m) = (b0 P(n, m+1) + b1 P(n+1, m+2) [+ 1]) - ((a0 + a1 x[n]) + a2 x[n+1])    if iteration n - S - m exists,
+//             = P(n, m+1)                                                                   otherwise,
+// only needs its right-hand neighbour two sections earlier, so lane n carries output n (and
+// complex cells 2n, 2n+1), walks m = S-1 .. 0 and fetches the neighbour's previous value
+// from lane n + 1: every lane runs the literal operations of its own cells, all at once.
+// Bit-identical to demod_heads (same operations on the same values).
+constexpr int kFusedSections = kFusedHeadSections;  // sections per stage chunk_head handles (degrees <= 8)
+
+__device__ __forceinline__ float lane_read(float v, uint32_t src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int) (src_lane << 2), __float_as_int(v)));
+}
+
+template <bool PLUS_ONE>
+__device__ __forceinline__ float section_update(const float (&row)[6], float cur, float next, float x0, float x1) {
+    float t = row[0] * cur + row[1] * next;
+    if constexpr (PLUS_ONE) t = t + 1.0f;
+    return t - (row[3] + row[4] * x0 + row[5] * x1);
+}
+
+template <int COND, bool S16>
+__device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane) {
+    // the segment's own stores (among them the interior-formula values of this row's first
+    // lanes, which are overwritten below) are complete before anything here is stored
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int Si = a.sec_in, So = a.sec_out;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(chunk) + lane;
+    const uint32_t w0 = w[0], w1 = w[1];
+    // complex samples 2n, 2n+1, 2n+2 of the chunk, n = lane
+    const float x0r = unpack_byte<COND>((uint8_t) w0, a.scale), x0i = unpack_byte<COND>((uint8_t) (w0 >> 8), a.scale);
+    const float x1r = unpack_byte<COND>((uint8_t) (w0 >> 16), a.scale), x1i = unpack_byte<COND>((uint8_t) (w0 >> 24), a.scale);
+    const float x2r = unpack_byte<COND>((uint8_t) w1, a.scale), x2i = unpack_byte<COND>((uint8_t) (w1 >> 8), a.scale);
+    float Ar = x0r, Ai = x0i, Br = x1r, Bi = x1i;  // what the discriminator reads: samples, or the complex stage's cells 2n, 2n+1
+    float y0 = 0.f;                                // what the output stage finds in its cell n
+    if (Si > 0) {
+        // complex stage, cells A = 2n and B = 2n + 1; c* = P(cell, m+1), p* = P(cell, m+2)
+        float cAr = 0.f, cAi = 0.f, cBr = 0.f, cBi = 0.f, pAr = 0.f, pAi = 0.f, pBr = 0.f, pBi = 0.f;
+        const int cellA = 2 * (int) lane;
+#pragma unroll
+        for (int m = kFusedSections - 1; m >= 0; --m) {
+            if (m < Si) {
+                const float nBr = from_next_lane(pAr, 0.f), nBi = from_next_lane(pAi, 0.f);  // cell 2n + 2 lives in the next lane
+                const float vAr = section_update<true>(a.sos_in[m], cAr, pBr, x0r, x1r);
+                const float vAi = section_update<false>(a.sos_in[m], cAi, pBi, x0i, x1i);
+                const float vBr = section_update<true>(a.sos_in[m], cBr, nBr, x1r, x2r);
+                const float vBi = section_update<false>(a.sos_in[m], cBi, nBi, x1i, x2i);
+                const bool exA = cellA - Si - m >= 0, exB = cellA + 1 - Si - m >= 0;
+                pAr = cAr; pAi = cAi; pBr = cBr; pBi = cBi;
+                cAr = exA ? vAr : cAr; cAi = exA ? vAi : cAi;
+                cBr = exB ? vBr : cBr; cBi = exB ? vBi : cBi;
+            }
+        }
+        Ar = cAr; Ai = cAi; Br = cBr; Bi = cBi;
+        // overflow cells K + t, t = lane: written by the stage's last 2 Si - 1 iterations into the
+        // buffer the output stage starts from.  Their "input" is the head of the stage's own
+        // output, x[K + t] == z[t] (the buffers are adjacent, src/matrix.c:260-264) -- or zeros
+        // when the stage reads a buffer of its own (-q2).  Cell t lives in lane t / 2.
+        const uint32_t s0 = lane >> 1, s1 = (lane + 1u) >> 1;
+        const float rA0 = lane_read(Ar, s0), rB0 = lane_read(Br, s0), iA0 = lane_read(Ai, s0), iB0 = lane_read(Bi, s0);
+        const float rA1 = lane_read(Ar, s1), rB1 = lane_read(Br, s1), iA1 = lane_read(Ai, s1), iB1 = lane_read(Bi, s1);
+        const bool own = a.in_separate == 0;
+        const float ztr = own ? ((lane & 1u) ? rB0 : rA0) : 0.f, zti = own ? ((lane & 1u) ? iB0 : iA0) : 0.f;
+        const float zur = own ? ((lane & 1u) ? rA1 : rB1) : 0.f, zui = own ? ((lane & 1u) ? iA1 : iB1) : 0.f;
+        float cr = 0.f, ci = 0.f, pr = 0.f, pi = 0.f;
+#pragma unroll
+        for (int m = kFusedSections - 1; m >= 0; --m) {
+            if (m < Si) {
+                const float nr = from_next_lane(pr, 0.f), ni = from_next_lane(pi, 0.f);
+                const float vr = section_update<true>(a.sos_in[m], cr, nr, ztr, zur);
+                const float vi = section_update<false>(a.sos_in[m], ci, ni, zti, zui);
+                const bool ex = (int) lane <= m + Si - 1;  // iteration K - 2 Si + 1 + (t - 1 + Si - m) is one of the last 2 Si - 1
+                pr = cr; pi = ci;
+                cr = ex ? vr : cr; ci = ex ? vi : ci;
+            }
+        }
+        // output cell n starts from overflow cell n / 2: its real part (n even) or imaginary part (n odd)
+        const float ovr = lane_read(cr, lane >> 1), ovi = lane_read(ci, lane >> 1);
+        y0 = (lane & 1u) ? ovi : ovr;
+    }
+    const float d0 = discriminate_literal(Ar, Ai, Br, Bi);
+    const float d1 = from_next_lane(d0, 0.f);
+    float cy = y0, py = y0;  // P(n, So) = P(n, So + 1) = what the cell held before
+#pragma unroll
+    for (int m = kFusedSections - 1; m >= 0; --m) {
+        if (m < So) {
+            const float ny = from_next_lane(py, 0.f);
+            const float v = section_update<true>(a.sos_out[m], cy, ny, d0, d1);
+            const bool ex = (int) lane - So - m >= 0;
+            py = cy;
+            cy = ex ? v : cy;
+        }
+    }
+    if (lane < 4u * a.head_quads) {
+        if constexpr (S16) __builtin_nontemporal_store(to_s16(cy, a.out_scale), reinterpret_cast<int16_t *>(a.out) + out_index + lane);
+        else __builtin_nontemporal_store(cy, reinterpret_cast<float *>(a.out) + out_index + lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // the fused streaming kernel
 // ---------------------------------------------------------------------------
 // Register budget: 8 wavefronts per SIMD (64 VGPRs).  The common stencils fit without
@@ -492,13 +590,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
     // interleaved segments, so that each XCD streams every kXcd-th segment of a compact window
     // instead of a contiguous kWavesPerBlock-segment piece of it.
     constexpr uint32_t kXcd = DEMOD_XCD_INTERLEAVE;
-#ifdef DEMOD_XCD_GRAIN   // experiment: contiguous pieces of this many segments per workgroup
-    constexpr uint32_t kGrain = DEMOD_XCD_GRAIN;
-    const uint32_t seg = (blockIdx.x / kXcd) * (kXcd * (uint32_t) kWavesPerBlock) + (wave / kGrain) * (kXcd * kGrain) +
-                         (blockIdx.x % kXcd) * kGrain + wave % kGrain;
-#else
     const uint32_t seg = (blockIdx.x / kXcd) * (kXcd * (uint32_t) kWavesPerBlock) + wave * kXcd + blockIdx.x % kXcd;
-#endif
 #else
     const uint32_t seg = blockIdx.x * (uint32_t) kWavesPerBlock + wave;
 #endif
@@ -506,7 +598,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
     // rows are numbered from the start of the chunk that encloses buffer row 0
     const uint32_t g0 = a.phase_rows;
     const uint32_t g1 = g0 + a.n_rows;
-    uint32_t gb = ((g0 >> a.seg_log2) + seg) << a.seg_log2;
+    const uint32_t gs = ((g0 >> a.seg_log2) + seg) << a.seg_log2;  // where the segment starts, clipped or not
+    uint32_t gb = gs;
     uint32_t ge = gb + (1u << a.seg_log2);
     gb = gb < g0 ? g0 : gb;
     ge = ge > g1 ? g1 : ge;
@@ -591,7 +684,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
         const uint32_t nlane = lane0_only ? 0u
                                : next_is_halo ? (lane < DEMOD_HALO_BYTES / 16u ? lane : 0u)
                                               : lane;
-#if DEMOD_EXACT_WAITS
         // ---- exchange lines in LDS (see LdsExchange) ------------------------
         constexpr int kExX = 2 * (TIN > 1 ? TIN - 1 : 0);  // floats a lane publishes per row: re, im of its first samples
         constexpr int kExD = TOUT - 1;                     // ... and its first discriminator outputs
@@ -618,147 +710,85 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void
         // operations in issue order, and when row k is needed exactly
         // kGroup-1-k younger loads and k stores have been issued after its
         // load -- kGroup-1 operations for every k.  Requirements kept below:
-        // straight-line code between a load and its wait, exactly one store
-        // per row (head lanes and rows past a clipped segment store to the
-        // scratch sink), wait statements that name the loaded registers.
+        // always kGroup + 1 loads (a clipped segment asks for row rb again in
+        // place of the rows it lacks; those are never computed, only waited for
+        // at the end), exactly one store per computed row, nothing else that
+        // touches vector memory before the last row is stored, wait statements
+        // that name the loaded registers.  tools/check_asm_waits.py replays the
+        // generated assembly against these rules.
         constexpr int nx = 2 * (TOUT - 1) + (TIN > 0 ? TIN - 1 : 0);
         const uint8_t *np = nbase + 16u * nlane;
-        u32x4 qn4 = {0, 0, 0, 0};
-        u32x2 qn2 = {0, 0};
-        uint32_t qn1 = 0;
-        if constexpr (nx > 4) asm volatile("global_load_dwordx4 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn4) : "v"(np) : "memory");
-        else if constexpr (nx > 2) asm volatile("global_load_dwordx2 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn2) : "v"(np) : "memory");
-        else asm volatile("global_load_dword %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn1) : "v"(np) : "memory");
-        u32x4 qa[kGroup];
+        // The body exists twice: FULL (all kGroup rows: every segment but the first and last of
+        // a launch, and every one when chunks are at least kGroup rows long) is straight-line
+        // code, so that hipcc schedules across the rows; the other form serves a clipped
+        // segment.  Each issues its own loads: registers of a load in flight must not cross a
+        // branch (hipcc would be free to copy them on the way).
+        auto segment = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            u32x4 qn4 = {0, 0, 0, 0};
+            u32x2 qn2 = {0, 0};
+            uint32_t qn1 = 0;
+            if constexpr (nx > 4) asm volatile("global_load_dwordx4 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn4) : "v"(np) : "memory");
+            else if constexpr (nx > 2) asm volatile("global_load_dwordx2 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn2) : "v"(np) : "memory");
+            else asm volatile("global_load_dword %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn1) : "v"(np) : "memory");
+            u32x4 qa[kGroup];
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const uint32_t row = re >= rb + 1u + (uint32_t) k ? re - 1u - (uint32_t) k : rb;
-            const uint8_t *rp = a.in + (uint64_t) row * kRowBytes + 16u * lane;
-            asm volatile("global_load_dwordx4 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qa[k]) : "v"(rp) : "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the look-ahead row was asked for first: kGroup younger loads may stay in flight
-        if constexpr (nx > 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn4) : "i"(kGroup) : "memory");
-        else if constexpr (nx > 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn2) : "i"(kGroup) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn1) : "i"(kGroup) : "memory");
-        {
-            uint4 qn = make_uint4(0, 0, 0, 0);
-            if constexpr (nx > 4) qn = make_uint4(qn4.x, qn4.y, qn4.z, qn4.w);
-            else if constexpr (nx > 2) { qn.x = qn2.x; qn.y = qn2.y; }
-            else qn.x = qn1;
-            Halo h = halo;
-#ifndef DEMOD_EXP_NO_LOOKAHEAD   // experiment: a segment whose look-ahead costs nothing (wrong results)
-            next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
-#else
-            h.d[0] = __uint_as_float(qn.x);
-#endif
-            // the first row processed uses line 0 and, in lane 63, slot 0 of line 1
-#pragma unroll
-            for (int j = 0; j < kExX / 2; ++j) {
-                wr_x[1][2 * j] = have_next ? h.xr[j] : kPastEnd;
-                wr_x[1][2 * j + 1] = have_next ? h.xi[j] : kPastEnd;
+            for (int k = 0; k < kGroup; ++k) {
+                const uint32_t row = (FULL || re >= rb + 1u + (uint32_t) k) ? re - 1u - (uint32_t) k : rb;
+                const uint8_t *rp = a.in + (uint64_t) row * kRowBytes + 16u * lane;
+                asm volatile("global_load_dwordx4 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qa[k]) : "v"(rp) : "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // the look-ahead row was asked for first: kGroup younger loads may stay in flight
+            if constexpr (nx > 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn4) : "i"(kGroup) : "memory");
+            else if constexpr (nx > 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn2) : "i"(kGroup) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn1) : "i"(kGroup) : "memory");
+            {
+                uint4 qn = make_uint4(0, 0, 0, 0);
+                if constexpr (nx > 4) qn = make_uint4(qn4.x, qn4.y, qn4.z, qn4.w);
+                else if constexpr (nx > 2) { qn.x = qn2.x; qn.y = qn2.y; }
+                else qn.x = qn1;
+                Halo h = halo;
+                next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
+                // the first row processed uses line 0 and, in lane 63, slot 0 of line 1
 #pragma unroll
-            for (int j = 0; j < TOUT - 1; ++j) wr_d[1][j] = have_next ? h.d[j] : 0.f;
-        }
-        float lead = kAtanLead;
-        asm volatile("" : "+v"(lead));  // one register for the whole segment, see fast_atan2
+                for (int j = 0; j < kExX / 2; ++j) {
+                    wr_x[1][2 * j] = have_next ? h.xr[j] : kPastEnd;
+                    wr_x[1][2 * j + 1] = have_next ? h.xi[j] : kPastEnd;
+                }
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const bool live = re >= rb + 1u + (uint32_t) k;  // wave-uniform
-            const uint32_t r = live ? re - 1u - (uint32_t) k : rb;
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
-            float y[4];
-            LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1]};
-            process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
-            // the first lanes of a chunk's first row hold outputs that belong to the
-            // chunk-head kernel; rows past a clipped segment are recomputed copies of
-            // row rb: both store to the sink so that the store count stays exact
-            char *dst = out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane);
-            if ((((g0 + r) & rpc_mask) == 0u) || !live) {  // wave-uniform, rare
-                const bool to_sink = !live || lane < a.head_quads;
-                dst = to_sink ? reinterpret_cast<char *>(a.sink + 4u * lane) : dst;
+                for (int j = 0; j < TOUT - 1; ++j) wr_d[1][j] = have_next ? h.d[j] : 0.f;
             }
-            store_quad<S16>(dst, y, a.out_scale);
-        }
-#else
-        // only the dwords the look-ahead reads are loaded (a wider load whose
-        // upper registers are dead makes hipcc wait for it before reusing them)
-        uint4 qn = make_uint4(0, 0, 0, 0);
-        {
-            constexpr int nx = 2 * (TOUT - 1) + (TIN > 0 ? TIN - 1 : 0);
-            const uint32_t *np = reinterpret_cast<const uint32_t *>(nbase) + 4u * nlane;
-            if constexpr (nx > 8 || nx > 4) {
-                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(np));
-                qn = make_uint4(v.x, v.y, v.z, v.w);
-            } else if constexpr (nx > 2) {
-                const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(np));
-                qn.x = v.x;
-                qn.y = v.y;
-            } else {
-                qn.x = __builtin_nontemporal_load(np);
-            }
-        }
-        uint4 q[kGroup];
+            float lead = kAtanLead;
+            asm volatile("" : "+v"(lead));  // one register for the whole segment, see fast_atan2
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const uint32_t row = re >= rb + 1u + (uint32_t) k ? re - 1u - (uint32_t) k : rb;
-#if defined(DEMOD_EXP_NOMEM)      // experiment: arithmetic alone (inputs made up from the lane id)
-            q[k] = make_uint4(lane * 2654435761u + row, lane * 40503u + k, lane ^ (row * 97u), lane + 77u * row);
-#else
-            q[k] = load(row);
-#endif
-        }
-        // every load above is issued before any computing starts (a scheduling
-        // barrier: nothing moves across it; it does not wait for anything)
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            Halo h = halo;
-            next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
-#pragma unroll
-            for (int j = 0; j < kMaxTaps - 1; ++j) {
-                halo.xr[j] = have_next ? h.xr[j] : kPastEnd;
-                halo.xi[j] = have_next ? h.xi[j] : kPastEnd;
-                halo.d[j] = have_next ? h.d[j] : 0.f;
-            }
-        }
-
-        // All rows are computed before any result is stored: while loads are still
-        // pending no store is, so hipcc's exact vmcnt(N) waits for the rows' loads
-        // are also exact for the hardware (it counts loads and stores on one
-        // counter and would otherwise make a row wait for an earlier row's store).
-        float y[kGroup][4];
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const bool live = re >= rb + 1u + (uint32_t) k;  // wave-uniform
-            if (live) {
-#if defined(DEMOD_EXP_COPYONLY)   // experiment: memory pattern alone
-                y[k][0] = __uint_as_float(q[k].x); y[k][1] = __uint_as_float(q[k].y);
-                y[k][2] = __uint_as_float(q[k].z); y[k][3] = __uint_as_float(q[k].w);
-#else
-                RegisterExchange ex{halo};
-                process_row<TIN, TOUT, COND, false>(q[k], a, ex, 16, kAtanLead, y[k]);
-#endif
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const bool live = re >= rb + 1u + (uint32_t) k;
-            if (live) {
+            for (int k = 0; k < kGroup; ++k) {
+                if constexpr (!FULL) {
+                    // rows a clipped segment lacks are not computed (wave-uniform; the computed
+                    // rows come first, so the counts above hold for each of them)
+                    if (re < rb + 1u + (uint32_t) k) break;
+                }
                 const uint32_t r = re - 1u - (uint32_t) k;
-                // the first lanes of a chunk's first row hold outputs that belong to
-                // the chunk-head kernel
-                const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
-#if defined(DEMOD_EXP_NOMEM)
-                if (!head && y[k][0] == 123456.789f)  // keeps the results live
-                    store_quad<S16>(out_address<S16>(a.out, 4u * lane), y[k], a.out_scale);
-#else
-                if (!head)
-                    store_quad<S16>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane), y[k], a.out_scale);
-#endif
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
+                float y[4];
+                LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1]};
+                process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
+                // (the first lanes of a chunk's first row hold interior-formula values for
+                // outputs that are not interior: chunk_head / demod_heads overwrites them)
+                store_quad<S16>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane), y, a.out_scale);
             }
-        }
-#endif  // DEMOD_EXACT_WAITS
+            if constexpr (!FULL) {
+                // the stand-in loads of the missing rows land in registers hipcc believes free
+                // from here on: wait for them before anything else runs
+#pragma unroll
+                for (int k = 0; k < kGroup; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa[k]) : : "memory");
+            }
+        };
+        if (re - rb == (uint32_t) kGroup) segment(std::true_type{});
+        else segment(std::false_type{});
+        // ---- the chunk's head, if this segment starts a chunk -----------------
+        if (a.fused_heads != 0u && (gs & rpc_mask) == 0u && gs >= g0)
+            chunk_head<COND, S16>(a, a.in + (uint64_t) rb * kRowBytes, (uint64_t) rb * kRowOutputs, lane);
     }
 }
 

@@ -112,7 +112,8 @@ class Demodulator:
 
     def _check(self, rc: int, what: str) -> None:
         if rc != 0:
-            assert self._lib.demod_last_error_code(self._ctx) == rc   # the message belongs to this failure
+            code = getattr(self._lib, "demod_last_error_code", None)
+            assert code is None or code(self._ctx) == rc   # the message belongs to this failure
             raise DemodError(f"{what} failed ({rc}): {self._lib.demod_last_error(self._ctx).decode()}")
 
     # -- introspection ----------------------------------------------------------
@@ -152,6 +153,12 @@ class Demodulator:
     @property
     def output_dtype(self):
         return np.int16 if self._lib.demod_output_bytes(self._ctx) == 2 else np.float32
+
+    def set_head_mode(self, mode: int) -> None:
+        """Where chunk heads are replayed: 1 inside the streaming kernel, 0 demod_heads kernel, -1 automatic."""
+        fn = getattr(self._lib, "demod_set_head_mode", None)
+        if fn is not None:      # absent from older builds selected with DEMOD_HIP_LIBRARY
+            self._check(fn(self._ctx, mode), "demod_set_head_mode")
 
     def set_piece_rows(self, rows: int) -> None:
         self._check(self._lib.demod_set_piece_rows(self._ctx, rows), "demod_set_piece_rows")

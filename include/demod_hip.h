@@ -200,6 +200,12 @@ int demod_output_bytes(const demod_ctx *ctx);
  * it needs a fresh look-ahead; power of two, 0 = automatic. */
 int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows);
 
+/* Tuning knob: where the first outputs of every chunk (partial sections, overflow
+ * cells; not interior) are replayed: 1 = by the wavefront of the streaming kernel that
+ * owns the chunk's first row (one kernel per dispatch), 0 = by the demod_heads kernel
+ * behind it, -1 = automatic by chunk size (default).  Results are bit-identical. */
+int demod_set_head_mode(demod_ctx *ctx, int mode);
+
 /* Tuning knob: rows per dispatch of the fused kernel (a call covering more is
  * cut into that many back-to-back dispatches); power of two, 0 = default
  * (2^21 rows = 2 GiB of input). */

@@ -6,10 +6,12 @@ own s_waitcnt bookkeeping, and waits for them with hand-counted `s_waitcnt
 vmcnt(N)` statements.  The hazard is the compiler
 reading or overwriting a destination register of such a load before the wait
 that covers it (it believes the value is there at ;;#ASMEND).  This script
-compiles kernels.hip to gfx950 assembly and replays every demod_rows function:
-vector-memory operations retire in issue order, so after `s_waitcnt vmcnt(N)`
-everything but the N youngest operations has landed; any instruction that
-touches a register of a load that has not landed yet is reported.
+compiles kernels.hip to gfx950 assembly and replays every demod_rows function
+along EVERY path of its control-flow graph (rows of a clipped segment are
+skipped by wave-uniform branches): vector-memory operations retire in issue
+order, so after `s_waitcnt vmcnt(N)` everything but the N youngest operations
+has landed; any instruction that touches a register of a load that has not
+landed yet is reported.
 
     python tools/check_asm_waits.py            # exit code 1 on a violation
 """
@@ -41,60 +43,86 @@ def regs(text: str) -> set[int]:
     return out
 
 
-def check_function(name: str, lines: list[str]) -> list[str]:
-    problems = []
-    queue: list[tuple[str, set[int]]] = []   # in-flight vector-memory ops, oldest first: (kind, dest regs)
+def parse(lines):
+    """[(line number, op, operands, in_asm)] of the function's instructions and {label: index}."""
+    insts, labels = [], {}
     in_asm = False
-    n_asm_loads = n_waits = 0
     for ln, raw in lines:
-        line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
-        if line.startswith(";;#ASMSTART"):
+        st = raw.strip()
+        if st.startswith(";;#ASMSTART"):
             in_asm = True
             continue
-        if line.startswith(";;#ASMEND"):
+        if st.startswith(";;#ASMEND"):
             in_asm = False
             continue
-        if not line or line.endswith(":") or line.startswith("."):
+        line = raw.split(";")[0].strip()
+        if not line:
+            continue
+        if line.endswith(":"):
+            labels[line[:-1]] = len(insts)
+            continue
+        if line.startswith("."):
             continue
         op = line.split()[0]
-        operands = line[len(op):]
-        if op.startswith("s_waitcnt"):
-            m = re.search(r"vmcnt\((\d+)\)", line)
-            if m:
-                n = int(m.group(1))
-                if in_asm:
-                    n_waits += 1
-                while len(queue) > n:
-                    queue.pop(0)
-            continue
-        pending = set().union(*(r for k, r in queue if k == "asmload")) if queue else set()
-        if op.startswith(("global_load", "buffer_load", "flat_load")):
-            parts = operands.split(",")
-            dest = regs(parts[0])
-            touched = regs(",".join(parts[1:]))
-            if touched & pending or dest & pending:
-                problems.append(f"{name}:{ln}: `{line}` touches registers of a load still in flight: "
-                                f"{sorted((touched | dest) & pending)}")
-            queue.append(("asmload" if in_asm else "load", dest))
-            n_asm_loads += in_asm
-            continue
-        if op.startswith(("global_store", "buffer_store", "flat_store")):
-            touched = regs(operands)
-            if touched & pending:
-                problems.append(f"{name}:{ln}: `{line}` reads registers of a load still in flight: "
-                                f"{sorted(touched & pending)}")
-            queue.append(("store", set()))
-            continue
-        if op.startswith(("s_endpgm",)):
-            queue.clear()   # a path ends; the next basic block listed starts from its own predecessors
-            continue
-        if op.startswith(("s_", "ds_")) and not op.startswith("ds_"):
-            continue
-        touched = regs(operands)
-        if touched & pending:
-            problems.append(f"{name}:{ln}: `{line}` touches registers of a load still in flight: "
-                            f"{sorted(touched & pending)}")
-    return problems, n_asm_loads, n_waits
+        insts.append((ln, op, line[len(op):], in_asm, line))
+    return insts, labels
+
+
+def check_function(name: str, lines: list) -> tuple:
+    """Walk every path through the function's control-flow graph (both outcomes of each
+    conditional branch) with the queue of in-flight vector-memory operations as state."""
+    insts, labels = parse(lines)
+    problems: dict = {}
+    n_asm_loads = sum(1 for (_, op, _, in_asm, _) in insts if in_asm and op.startswith("global_load"))
+    n_waits = sum(1 for (_, op, _, in_asm, line) in insts if in_asm and op.startswith("s_waitcnt") and "vmcnt" in line)
+    seen = set()
+    stack = [(0, ())]     # (instruction index, queue: tuple of (kind, frozenset(dest regs)), oldest first)
+    steps = 0
+    while stack:
+        pc, queue = stack.pop()
+        queue = list(queue)
+        while pc < len(insts):
+            key = (pc, tuple(queue))
+            if key in seen:
+                break
+            seen.add(key)
+            steps += 1
+            if steps > 2_000_000:
+                problems[(name, -1)] = f"{name}: path enumeration did not terminate"
+                return list(problems.values()), n_asm_loads, n_waits
+            ln, op, operands, in_asm, line = insts[pc]
+            nxt = pc + 1
+            if op.startswith("s_waitcnt"):
+                m = re.search(r"vmcnt\((\d+)\)", line)
+                if m:
+                    del queue[: max(0, len(queue) - int(m.group(1)))]
+            elif op == "s_endpgm":
+                break
+            elif op == "s_branch":
+                nxt = labels[operands.strip()]
+            elif op.startswith("s_cbranch"):
+                stack.append((labels[operands.strip().split(",")[-1].strip()], tuple(queue)))
+            elif op.startswith(("s_", "ds_")) and not op.startswith("ds_"):
+                pass
+            else:
+                pending = set().union(*(r for k, r in queue if k == "asmload")) if queue else set()
+                if op.startswith(("global_load", "buffer_load", "flat_load")):
+                    parts = operands.split(",")
+                    dest = regs(parts[0])
+                    touched = regs(",".join(parts[1:])) | dest
+                    queue.append(("asmload" if in_asm else "load", frozenset(dest)))
+                elif op.startswith(("global_store", "buffer_store", "flat_store")):
+                    touched = regs(operands)
+                    queue.append(("store", frozenset()))
+                else:
+                    touched = regs(operands)
+                if touched & pending:
+                    problems[(name, ln)] = (f"{name}:{ln}: `{line}` touches registers of a load still in flight: "
+                                            f"{sorted(touched & pending)}")
+                if len(queue) > 48:          # loops of the bounds-checked build (no asm loads there)
+                    del queue[: len(queue) - 48]
+            pc = nxt
+    return list(problems.values()), n_asm_loads, n_waits
 
 
 def main() -> int:

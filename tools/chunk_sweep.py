@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""GPU box: throughput vs chunk size (-b): small chunks shift work to the chunk-head kernel."""
+"""GPU box: throughput vs chunk size (-b) -- every chunk has a head to replay.
+    python tools/chunk_sweep.py [head_mode]     head_mode: -1 automatic (default), 0 demod_heads kernel, 1 in the streaming kernel"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import demodulator_amd as dm
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else -1
 n = 2 << 29
 iq = torch.empty(n, dtype=torch.uint8, device="cuda"); out = torch.empty(n // 4, dtype=torch.float32, device="cuda")
 for flags in (dict(), dict(lowpass_in=12500.0, lowpass_out=6500.0)):
-    for B in (256, 1024, 4096, 16384, 65536, 262144, 4 << 20):
+    for B in (256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 4 << 20):
         d = dm.Demodulator(dm.Options(buf_size=B, **flags))
+        d.set_head_mode(mode)
         d.synth_fill(iq, 0, 7)
         for _ in range(3):
             d.process(iq, out)
