@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DEMOD_HIP_LIBRARY selects another build of the same library (kernel tuning experiments)
 LIB_PATH = os.environ.get("DEMOD_HIP_LIBRARY") or os.path.join(_HERE, "libdemod_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 HALO_BYTES = 64
 ROW_BYTES = 1024
 
@@ -28,6 +28,8 @@ EXPORTS = (
     "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
     "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
     "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_set_head_mode",
+    "demod_stream_depth", "demod_ring_slots_for", "demod_ring_create", "demod_ring_destroy", "demod_ring_input",
+    "demod_ring_commit", "demod_ring_collect", "demod_ring_release",
 )
 
 
@@ -107,6 +109,14 @@ def load() -> C.CDLL:
         "demod_enable_timing": (None, [vp, i32]),
         "demod_last_error_code": (i32, [vp]),
         "demod_set_head_mode": (i32, [vp, i32]),
+        "demod_stream_depth": (i32, []),
+        "demod_ring_slots_for": (u32, [u64]),
+        "demod_ring_create": (i32, [vp, vp, u32, C.POINTER(vp)]),
+        "demod_ring_destroy": (None, [vp]),
+        "demod_ring_input": (vp, [vp]),
+        "demod_ring_commit": (i32, [vp, u64, i32]),
+        "demod_ring_collect": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
+        "demod_ring_release": (i32, [vp]),
         "demod_design_magnitude_bound": (C.c_double, [C.POINTER(Params)]),
     }
     experiment = bool(os.environ.get("DEMOD_HIP_LIBRARY"))

@@ -1,5 +1,5 @@
 // api.cpp -- the C ABI declared in include/demod_hip.h: contexts, the device
-// hot-path entry point, the pinned double-buffered host path, helpers.
+// hot-path entry point, helpers.  (The host-buffer paths: host.cpp.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -11,9 +11,7 @@
 #include <thread>
 #include <vector>
 
-#include "demod_hip.h"
-#include "kernels.h"
-#include "plan.h"
+#include "ctx.h"
 
 using namespace demod;
 
@@ -22,34 +20,11 @@ namespace {
 std::mutex g_err_mutex;
 std::string g_create_error;
 
-constexpr uint64_t kStageBytes = 32ull << 20;  // host path: input bytes per staged piece
 constexpr uint32_t kTinyThreads = 8192;
 constexpr uint32_t kPieceRows = 1u << 21;       // rows per demod_rows launch (2 GiB of input)
 // chunk heads inside the streaming kernel for chunks of at least this many rows (below, the
 // demod_heads kernel is cheaper), see heads_are_fused()
 constexpr uint64_t kFusedMinRows = 128;
-
-// Host-side staging copy (pageable <-> pinned): one thread moves ~10 GB/s, a PCIe Gen5
-// x16 link twice that in each direction, so large pieces are split over a few threads.
-void staged_copy(void *dst, const void *src, size_t n) {
-    constexpr size_t kMinPerThread = 4u << 20;
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t parts = std::min<size_t>({(size_t) 4, n / kMinPerThread, hw ? hw : 1});
-    if (parts < 2) {
-        memcpy(dst, src, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    const size_t step = (n / parts + 4095) & ~(size_t) 4095;
-    for (size_t p = 1; p < parts; ++p) {
-        const size_t off = p * step;
-        if (off >= n) break;
-        const size_t len = std::min(step, n - off);
-        th.emplace_back([=] { memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, len); });
-    }
-    memcpy(dst, src, std::min(step, n));
-    for (auto &t : th) t.join();
-}
 
 uint32_t log2u(uint64_t v) {
     uint32_t l = 0;
@@ -58,68 +33,6 @@ uint32_t log2u(uint64_t v) {
 }
 
 }  // namespace
-
-struct demod_ctx {
-    Options opt;
-    Plan plan;
-    int device = 0;
-    std::string err;
-
-    bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
-    int head_mode = -1;     // demod_set_head_mode: -1 automatic, 0 demod_heads kernel, 1 inside the streaming kernel
-    uint32_t seg_rows = 0;  // 0 = automatic
-    uint32_t piece_rows = kPieceRows;  // rows per demod_rows dispatch
-    bool out_s16 = false;              // results leave as int16 (demod_set_output_format)
-    float out_scale = 1.f;
-    uint32_t out_bytes() const { return out_s16 ? 2u : 4u; }
-    int last_row_launches = 0;  // demod_rows dispatches issued by the most recent process call
-
-    // kernel timing (HIP events on the launch stream)
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
-
-    // scratch for the whole-chunk literal path (chunks < 1 KiB): ONE buffer, thread t
-    // always uses work + t * stride, so launches on different streams (the host path's
-    // slots) are ordered through tiny_done: each waits for the one before it
-    float *tiny_work = nullptr;
-    uint64_t tiny_stride = 0;
-    hipEvent_t tiny_done = nullptr;
-    bool tiny_pending = false;
-
-    // host path staging: two slots, each pinned in/out + device in/out + stream
-    struct Slot {
-        void *h_in = nullptr, *h_out = nullptr, *h_halo = nullptr, *d_in = nullptr, *d_out = nullptr, *d_halo = nullptr;
-        hipStream_t stream = nullptr;
-        uint64_t out_floats = 0;  // results waiting in h_out (count, in the output format)
-        char *dst = nullptr;      // where they go
-    } slot[2];
-    bool slots_ready = false;
-    int submit_slot = 0;   // streaming form: next slot to fill
-    int collect_slot = 0;  // oldest slot not yet collected
-    int in_flight = 0;
-
-    int err_code = DEMOD_OK;  // code of the failure `err` describes (demod_last_error_code)
-    bool fail(int code, const char *what, hipError_t e = hipSuccess) {
-        char buf[384];
-        if (e != hipSuccess)
-            snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-        else
-            snprintf(buf, sizeof buf, "%s", what);
-        err = buf;
-        err_code = code;
-        return false;
-    }
-};
-
-#define HIP_TRY(ctx, call)                               \
-    do {                                                 \
-        hipError_t e_ = (call);                          \
-        if (e_ != hipSuccess) {                          \
-            (ctx)->fail(DEMOD_E_HIP, #call, e_);         \
-            return DEMOD_E_HIP;                          \
-        }                                                \
-    } while (0)
 
 extern "C" {
 
@@ -159,6 +72,7 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
     *out = nullptr;
     demod_ctx *ctx = new (std::nothrow) demod_ctx;
     if (!ctx) return create_fail(DEMOD_E_NOMEM, "out of memory");
+    ctx->piece_rows = kPieceRows;
     ctx->opt = options_from_params(*p);
     std::string err;
     if (!build_plan(ctx->opt, ctx->plan, err)) {
@@ -190,16 +104,7 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
 void demod_destroy(demod_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
-    for (auto &s : ctx->slot) {
-        if (s.stream) (void) hipStreamSynchronize(s.stream);
-        if (s.h_in) (void) hipHostFree(s.h_in);
-        if (s.h_out) (void) hipHostFree(s.h_out);
-        if (s.h_halo) (void) hipHostFree(s.h_halo);
-        if (s.d_in) (void) hipFree(s.d_in);
-        if (s.d_out) (void) hipFree(s.d_out);
-        if (s.d_halo) (void) hipFree(s.d_halo);
-        if (s.stream) (void) hipStreamDestroy(s.stream);
-    }
+    host_pipe_destroy(ctx);
     for (auto &p : ctx->timed) {
         (void) hipEventDestroy(p.first);
         (void) hipEventDestroy(p.second);
@@ -229,8 +134,8 @@ int demod_set_output_format(demod_ctx *ctx, int format, float scale) {
         ctx->fail(DEMOD_E_INVAL, "output format must be DEMOD_OUT_F32 or DEMOD_OUT_S16 with a positive finite scale");
         return DEMOD_E_INVAL;
     }
-    if (ctx->in_flight) {
-        ctx->fail(DEMOD_E_INVAL, "output format cannot change while submitted pieces are uncollected");
+    if (host_pipe_busy(ctx) || ctx->rings) {
+        ctx->fail(DEMOD_E_INVAL, "output format cannot change while submitted pieces are uncollected or a ring is open");
         return DEMOD_E_INVAL;
     }
     ctx->out_s16 = format == DEMOD_OUT_S16;
@@ -602,156 +507,6 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4 * ob, stream);
         if (rc) return rc;
     }
-    return DEMOD_OK;
-}
-
-// ---------------------------------------------------------------------------
-// host-buffer path: pinned double buffering, hipMemcpyAsync on two streams
-// ---------------------------------------------------------------------------
-
-static int ensure_slots(demod_ctx *ctx) {
-    if (ctx->slots_ready) return DEMOD_OK;
-    for (auto &s : ctx->slot) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_in, kStageBytes, hipHostMallocDefault));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_out, kStageBytes, hipHostMallocDefault));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_halo, DEMOD_HALO_BYTES, hipHostMallocDefault));
-        HIP_TRY(ctx, hipMalloc(&s.d_in, kStageBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_out, kStageBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_halo, DEMOD_HALO_BYTES));
-    }
-    ctx->slots_ready = true;
-    return DEMOD_OK;
-}
-
-static int drain_slot(demod_ctx *ctx, demod_ctx::Slot &s) {
-    if (!s.out_floats) return DEMOD_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    staged_copy(s.dst, s.h_out, s.out_floats * ctx->out_bytes());
-    s.out_floats = 0;
-    return DEMOD_OK;
-}
-
-int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, void *h_out_v,
-                       const demod_span *span) {
-    char *h_out = static_cast<char *>(h_out_v);
-    if (!ctx) return DEMOD_E_INVAL;
-    if (n_bytes == 0) return DEMOD_OK;
-    if (!h_in_v || !h_out || (n_bytes & 3)) {
-        ctx->fail(DEMOD_E_INVAL, "null buffer or n_bytes not a multiple of 4");
-        return DEMOD_E_INVAL;
-    }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_slots(ctx);
-    if (rc) return rc;
-
-    const uint8_t *h_in = static_cast<const uint8_t *>(h_in_v);
-    const uint64_t B = ctx->seamless ? (1ull << 41) : ctx->plan.chunk_bytes;
-    const uint64_t offset0 = span ? span->chunk_offset : 0;
-    const bool eos = span ? span->end_of_stream != 0 : true;
-    const uint8_t *tail_halo = span ? static_cast<const uint8_t *>(span->halo) : nullptr;
-
-    // pieces are whole chunks when a chunk fits the staging buffer, otherwise
-    // row-aligned cuts inside a chunk with the look-ahead taken from the host buffer
-    uint64_t piece = kStageBytes;
-    if (B <= kStageBytes) piece = kStageBytes / B * B;
-
-    uint64_t done = 0;
-    int which = 0;
-    while (done < n_bytes) {
-        uint64_t len = std::min(piece, n_bytes - done);
-        if (B <= kStageBytes && done == 0 && offset0) len = std::min(len, B - offset0);  // realign to chunks
-        demod_ctx::Slot &s = ctx->slot[which];
-        if ((rc = drain_slot(ctx, s))) return rc;
-
-        demod_span sp{};
-        sp.chunk_offset = B < kRowBytes ? 0 : (offset0 + done) % B;
-        const bool last = done + len == n_bytes;
-        sp.end_of_stream = last ? (eos ? 1u : 0u) : 0u;
-        const uint8_t *next = last ? tail_halo : h_in + done + len;
-        const bool ends_inside = B >= kRowBytes && ((offset0 + done + len) % B) != 0;
-        if (ends_inside && !sp.end_of_stream) {
-            if (last && !tail_halo) {
-                ctx->fail(DEMOD_E_INVAL, "buffer ends inside a chunk of a continuing stream: span.halo is required");
-                return DEMOD_E_INVAL;
-            }
-            // look-ahead bytes: what follows this piece in the host buffer, topped
-            // up from the caller's halo when the buffer itself runs out
-            uint8_t *hh = static_cast<uint8_t *>(s.h_halo);
-            memset(hh, 0, DEMOD_HALO_BYTES);
-            uint64_t have = 0;
-            if (!last) {
-                have = std::min<uint64_t>(DEMOD_HALO_BYTES, n_bytes - done - len);
-                memcpy(hh, next, have);
-            }
-            if (have < DEMOD_HALO_BYTES && tail_halo) memcpy(hh + have, tail_halo, DEMOD_HALO_BYTES - have);
-            HIP_TRY(ctx, hipMemcpyAsync(s.d_halo, hh, DEMOD_HALO_BYTES, hipMemcpyHostToDevice, s.stream));
-            sp.halo = s.d_halo;
-        }
-        staged_copy(s.h_in, h_in + done, len);
-        HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, len, hipMemcpyHostToDevice, s.stream));
-        rc = demod_process_device(ctx, s.d_in, len, s.d_out, &sp, s.stream);
-        if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, len / 4 * ctx->out_bytes(), hipMemcpyDeviceToHost, s.stream));
-        s.out_floats = len / 4;
-        s.dst = h_out + done / 4 * ctx->out_bytes();
-        done += len;
-        which ^= 1;
-    }
-    for (auto &s : ctx->slot)
-        if ((rc = drain_slot(ctx, s))) return rc;
-    return DEMOD_OK;
-}
-
-uint64_t demod_stream_capacity(void) { return kStageBytes; }
-
-int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, const demod_span *span) {
-    if (!ctx) return DEMOD_E_INVAL;
-    if (!h_in || n_bytes == 0 || (n_bytes & 3) || n_bytes > kStageBytes) {
-        ctx->fail(DEMOD_E_INVAL, "stream_submit: need 0 < n_bytes <= capacity, multiple of 4");
-        return DEMOD_E_INVAL;
-    }
-    if (ctx->in_flight >= 2) {
-        ctx->fail(DEMOD_E_INVAL, "stream_submit: both staging slots are in flight; collect first");
-        return DEMOD_E_INVAL;
-    }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_slots(ctx);
-    if (rc) return rc;
-    demod_ctx::Slot &s = ctx->slot[ctx->submit_slot];
-    demod_span sp{};
-    if (span) sp = *span;
-    else sp.end_of_stream = 1;
-    if (sp.halo) {  // host pointer here: stage it
-        memcpy(s.h_halo, sp.halo, DEMOD_HALO_BYTES);
-        HIP_TRY(ctx, hipMemcpyAsync(s.d_halo, s.h_halo, DEMOD_HALO_BYTES, hipMemcpyHostToDevice, s.stream));
-        sp.halo = s.d_halo;
-    }
-    memcpy(s.h_in, h_in, n_bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, n_bytes, hipMemcpyHostToDevice, s.stream));
-    rc = demod_process_device(ctx, s.d_in, n_bytes, s.d_out, &sp, s.stream);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, n_bytes / 4 * ctx->out_bytes(), hipMemcpyDeviceToHost, s.stream));
-    s.out_floats = n_bytes / 4;
-    s.dst = nullptr;
-    ctx->submit_slot ^= 1;
-    ctx->in_flight++;
-    return DEMOD_OK;
-}
-
-int demod_stream_collect(demod_ctx *ctx, const void **out, uint64_t *n_floats) {
-    if (!ctx || !out || !n_floats) return DEMOD_E_INVAL;
-    *out = nullptr;
-    *n_floats = 0;
-    if (ctx->in_flight == 0) return DEMOD_OK;  // nothing pending
-    demod_ctx::Slot &s = ctx->slot[ctx->collect_slot];
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    *out = s.h_out;
-    *n_floats = s.out_floats;
-    s.out_floats = 0;
-    ctx->collect_slot ^= 1;
-    ctx->in_flight--;
     return DEMOD_OK;
 }
 

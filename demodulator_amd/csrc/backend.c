@@ -3,20 +3,25 @@
  *
  * Hand-off protocol as the reference defines it (/root/reference/src/main.c:72-91,
  * src/matrix.c:236-242): the producer fills args->buf under the mutex, stores
- * the byte count in args->bufSize and posts `full`; the backend copies the bytes
- * out under the mutex and posts `empty`.  Unlike the reference consumer this one
+ * the byte count in args->bufSize and posts `full`; the backend takes the bytes
+ * under the mutex and posts `empty`.  Unlike the reference consumer this one
  * reads bufSize and exitFlag exactly once per hand-off, under the mutex, so the
  * last chunk is never lost or duplicated, and a final
- * partial chunk of r bytes yields r/4 outputs.  The chunk size B is read the same
- * way at start-up: the producer overwrites bufSize with the byte count of its
- * first read as soon as it wins the mutex (src/main.c:88), so what is found there
- * is either B or -- when the whole input is shorter than one chunk -- that count,
- * which is rounded up to the next power of two: a short only-chunk is filtered
- * as a chunk of its own length whatever B is, so the result is the same.
+ * partial chunk of r bytes yields r/4 outputs.
  *
- * GPU work is pipelined two deep (demod_stream_submit / _collect): while chunk
- * i is uploaded, demodulated and downloaded, chunk i-1 is written to outFile
- * and the producer reads chunk i+1.
+ * Ring mode (chunks of 1 KiB .. 32 MiB, the default): allocateBuffer hands the
+ * producer the first slot of a pinned RING of chunk-sized slots, and after every
+ * hand-off processMatrix points args->buf -- which the producer reads afresh
+ * under the mutex each time, main.c:76 -- at the next slot.  The producer's fread
+ * therefore lands in pinned memory next to the previous chunk: nothing is copied
+ * on the host, and runs of chunks travel as one upload + one hot-path call + one
+ * download (demod_ring_*: as many as arrived while the GPU was busy, at once
+ * when it is idle).  A second thread writes finished batches to outFile, in
+ * order, while the first keeps taking hand-offs.
+ *
+ * Copy mode (chunks below 1 KiB, DEMOD_SEAMLESS=1, or a hand-off buffer that did
+ * not come from this allocateBuffer): every hand-off is copied into a staging
+ * stage and pipelined three deep (demod_stream_submit / _collect).
  */
 #define _GNU_SOURCE
 #include "demod_backend.h"
@@ -33,8 +38,25 @@ static void die(const char *what, const char *detail) {
     exit(2);
 }
 
+/* the ring arena allocateBuffer made, waiting for the processMatrix that will use it
+ * (allocateBuffer has no context argument: include/matrix.h:61) */
+static struct {
+    pthread_mutex_t lock;
+    void *base;
+    size_t chunk;
+    unsigned slots;
+} g_arena = {PTHREAD_MUTEX_INITIALIZER, NULL, 0, 0};
+
 void allocateBuffer(void **buf, size_t len) {
-    if (demod_alloc_pinned(buf, len) != DEMOD_OK) die("allocateBuffer", demod_last_error(NULL));
+    const unsigned slots = demod_ring_slots_for(len);
+    if (demod_alloc_pinned(buf, slots ? (size_t) slots * len : len) != DEMOD_OK) die("allocateBuffer", demod_last_error(NULL));
+    if (slots) {
+        pthread_mutex_lock(&g_arena.lock);
+        g_arena.base = *buf;
+        g_arena.chunk = len;
+        g_arena.slots = slots;
+        pthread_mutex_unlock(&g_arena.lock);
+    }
 }
 
 /* sem_wait that gives up when the producer has stopped with an error flag
@@ -59,6 +81,77 @@ static int wait_full(demod_consumer_args *args) {
     }
 }
 
+/* ------------------------------------------------------------------ ring mode */
+
+struct writer {
+    demod_ring *ring;
+    demod_ctx *dm;
+    FILE *out;
+};
+
+static void *write_results(void *p) {
+    struct writer *w = p;
+    const size_t ob = (size_t) demod_output_bytes(w->dm);
+    for (;;) {
+        const void *res = NULL;
+        uint64_t n = 0;
+        if (demod_ring_collect(w->ring, &res, &n) != DEMOD_OK) die("collect", demod_last_error(w->dm));
+        if (!n) break; /* the stream has ended and everything was handed out */
+        fwrite(res, ob, n, w->out);
+        if (demod_ring_release(w->ring) != DEMOD_OK) die("release", demod_last_error(w->dm));
+    }
+    fflush(w->out);
+    return NULL;
+}
+
+static void run_ring(demod_consumer_args *args, demod_ctx *dm, void *arena, size_t chunk, unsigned slots) {
+    demod_ring *ring = NULL;
+    struct writer w;
+    pthread_t wt;
+    if (demod_ring_create(dm, arena, slots, &ring) != DEMOD_OK) die("ring", demod_last_error(dm));
+    w.ring = ring;
+    w.dm = dm;
+    w.out = args->outFile;
+    if (pthread_create(&wt, NULL, write_results, &w)) die("pthread_create", strerror(errno));
+    for (;;) {
+        size_t n;
+        int flag;
+        if (wait_full(args)) {
+            (void) demod_ring_commit(ring, 0, 1);
+            break;
+        }
+        pthread_mutex_lock(&args->mutex);
+        n = args->bufSize;
+        flag = args->exitFlag;
+        if (n > chunk) n = chunk;
+        n &= ~(size_t) 3;
+        if (flag == -2 || flag == -3) n = 0; /* read error: nothing valid in the buffer */
+        if (n < chunk && !flag) {
+            /* a short read that does not end the input cannot be laid next to the chunk
+             * that follows it; the reference's producers never make one (fread blocks until
+             * the chunk is full or the input ends) */
+            pthread_mutex_unlock(&args->mutex);
+            die("hand-off", "short read in the middle of the input");
+        }
+        if (demod_ring_commit(ring, n, flag != 0) != DEMOD_OK) {
+            pthread_mutex_unlock(&args->mutex);
+            die("commit", demod_last_error(dm));
+        }
+        if (!flag) args->buf = demod_ring_input(ring); /* the producer's next fread goes here */
+        pthread_mutex_unlock(&args->mutex);
+        sem_post(args->empty);
+        if (flag) break;
+    }
+    pthread_join(wt, NULL);
+    demod_ring_destroy(ring);
+    /* the hand-off buffer is the backend's (allocateBuffer made it; the reference's CUDA
+     * backend frees it the same way, cuda/matrix.cu:97) */
+    args->buf = NULL;
+    demod_free_pinned(arena);
+}
+
+/* ------------------------------------------------------------------ copy mode */
+
 static void drain(demod_ctx *dm, FILE *out) {
     const void *res = NULL;
     uint64_t n = 0;
@@ -66,63 +159,25 @@ static void drain(demod_ctx *dm, FILE *out) {
     if (n) fwrite(res, (size_t) demod_output_bytes(dm), n, out);
 }
 
-void *processMatrix(void *ctx) {
-    demod_consumer_args *args = ctx;
-    demod_params p;
-    demod_ctx *dm = NULL;
-    size_t chunk; /* B */
+static void run_copy(demod_consumer_args *args, demod_ctx *dm, size_t chunk, int seamless) {
+    const int depth = demod_stream_depth();
     int pending = 0;
-    /* DEMOD_SEAMLESS=1: filter the stream as one chunk (demod_set_seamless); not reference behaviour */
-    const char *env_seamless = getenv("DEMOD_SEAMLESS");
-    int seamless;
     unsigned char *held = NULL; /* seamless: the hand-off waiting for its look-ahead */
     size_t held_n = 0;
     uint64_t stream_pos = 0;
     unsigned char halo[DEMOD_HALO_BYTES];
 
-    pthread_mutex_lock(&args->mutex);
-    chunk = args->bufSize;
-    pthread_mutex_unlock(&args->mutex);
-    {
-        size_t b = 4;
-        while (b < chunk) b <<= 1;
-        chunk = b;
-    }
-    seamless = env_seamless && env_seamless[0] == '1' && chunk >= 1024;
-    demod_default_params(&p);
-    p.sample_rate = (double) args->sampleRate;
-    p.lowpass_in = (double) args->lowpassIn;
-    p.lowpass_out = (double) args->lowpassOut;
-    p.epsilon = (double) args->epsilon;
-    p.in_degree = (uint32_t) args->inFilterDegree;
-    p.out_degree = (uint32_t) args->outFilterDegree;
-    p.mode = args->mode;
-    p.buf_size = chunk;
-    if (demod_create(&p, 0, &dm) != DEMOD_OK) die("cannot start the MI355X demodulation path", demod_last_error(NULL));
-    if (chunk > demod_stream_capacity()) die("chunk size", "larger than the staging capacity of the streaming host path");
-
-    {
-        /* DEMOD_OUT_S16=<scale>: write signed 16-bit samples, clamp(y * scale, -1, 1) * 32767
-         * (demod_set_output_format); not reference behaviour */
-        const char *env_s16 = getenv("DEMOD_OUT_S16");
-        if (env_s16 && env_s16[0]) {
-            const float scale = strtof(env_s16, NULL);
-            if (demod_set_output_format(dm, DEMOD_OUT_S16, scale) != DEMOD_OK) die("DEMOD_OUT_S16", demod_last_error(dm));
-        }
-    }
     if (seamless) {
-        if (demod_set_seamless(dm, 1) != DEMOD_OK) die("seamless", demod_last_error(dm));
         held = malloc(chunk ? chunk : 1);
         if (!held) die("malloc", "out of memory");
     }
-
     for (;;) {
         size_t n;
         int flag;
         if (wait_full(args)) break;
         /* make room before touching the hand-off buffer: the oldest piece in
          * flight is written out while the producer is still parked on `empty` */
-        if (pending == 2) {
+        if (pending == depth) {
             drain(dm, args->outFile);
             --pending;
         }
@@ -133,10 +188,9 @@ void *processMatrix(void *ctx) {
         n &= ~(size_t) 3;
         if (!seamless) {
             /* copy out under the mutex, as the protocol requires: submit copies the
-             * bytes into a pinned staging slot and enqueues upload, kernel and
-             * download on that slot's stream without waiting for them.  Every
-             * hand-off is a chunk of its own: a short one (end of input) is
-             * filtered as a short chunk. */
+             * bytes into a pinned staging stage and enqueues upload, kernel and
+             * download without waiting for them.  Every hand-off is a chunk of its
+             * own: a short one (end of input) is filtered as a short chunk. */
             if (n && demod_stream_submit(dm, args->buf, n, NULL) != DEMOD_OK) {
                 pthread_mutex_unlock(&args->mutex);
                 die("submit", demod_last_error(dm));
@@ -178,7 +232,7 @@ void *processMatrix(void *ctx) {
         memset(&sp, 0, sizeof sp);
         sp.chunk_offset = stream_pos;
         sp.end_of_stream = 1;
-        if (pending == 2) {
+        if (pending == depth) {
             drain(dm, args->outFile);
             --pending;
         }
@@ -188,6 +242,71 @@ void *processMatrix(void *ctx) {
     while (pending--) drain(dm, args->outFile);
     fflush(args->outFile);
     free(held);
+}
+
+/* ----------------------------------------------------------------------------- */
+
+void *processMatrix(void *ctx) {
+    demod_consumer_args *args = ctx;
+    demod_params p;
+    demod_ctx *dm = NULL;
+    size_t chunk; /* B */
+    void *arena = NULL;
+    unsigned slots = 0;
+    /* DEMOD_SEAMLESS=1: filter the stream as one chunk (demod_set_seamless); not reference behaviour */
+    const char *env_seamless = getenv("DEMOD_SEAMLESS");
+    int seamless;
+
+    /* B: what allocateBuffer was asked for when the hand-off buffer is its ring (the
+     * producer may already have overwritten args->bufSize with the byte count of its
+     * first read, src/main.c:88); otherwise the field itself, read under the mutex and
+     * rounded up to a power of two -- if the producer got there first the whole input is
+     * shorter than one chunk, and a short only-chunk is filtered as a chunk of its own
+     * length whatever B is */
+    pthread_mutex_lock(&args->mutex);
+    chunk = args->bufSize;
+    pthread_mutex_lock(&g_arena.lock);
+    if (g_arena.base && g_arena.base == args->buf) {
+        arena = g_arena.base;
+        chunk = g_arena.chunk;
+        slots = g_arena.slots;
+        g_arena.base = NULL;
+    }
+    pthread_mutex_unlock(&g_arena.lock);
+    pthread_mutex_unlock(&args->mutex);
+    {
+        size_t b = 4;
+        while (b < chunk) b <<= 1;
+        chunk = b;
+    }
+    seamless = env_seamless && env_seamless[0] == '1' && chunk >= 1024;
+    demod_default_params(&p);
+    p.sample_rate = (double) args->sampleRate;
+    p.lowpass_in = (double) args->lowpassIn;
+    p.lowpass_out = (double) args->lowpassOut;
+    p.epsilon = (double) args->epsilon;
+    p.in_degree = (uint32_t) args->inFilterDegree;
+    p.out_degree = (uint32_t) args->outFilterDegree;
+    p.mode = args->mode;
+    p.buf_size = chunk;
+    if (demod_create(&p, 0, &dm) != DEMOD_OK) die("cannot start the MI355X demodulation path", demod_last_error(NULL));
+    if (chunk > demod_stream_capacity()) die("chunk size", "larger than the staging capacity of the streaming host path");
+
+    {
+        /* DEMOD_OUT_S16=<scale>: write signed 16-bit samples, clamp(y * scale, -1, 1) * 32767
+         * (demod_set_output_format); not reference behaviour */
+        const char *env_s16 = getenv("DEMOD_OUT_S16");
+        if (env_s16 && env_s16[0]) {
+            const float scale = strtof(env_s16, NULL);
+            if (demod_set_output_format(dm, DEMOD_OUT_S16, scale) != DEMOD_OK) die("DEMOD_OUT_S16", demod_last_error(dm));
+        }
+    }
+    if (seamless && demod_set_seamless(dm, 1) != DEMOD_OK) die("seamless", demod_last_error(dm));
+
+    if (arena && !seamless)
+        run_ring(args, dm, arena, chunk, slots);
+    else
+        run_copy(args, dm, chunk, seamless);
     demod_destroy(dm);
     return NULL;
 }

@@ -247,6 +247,10 @@ class Demodulator:
         buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(out.value)
         return np.frombuffer(buf, dtype=dt).copy()
 
+    def ring(self, slots: int | None = None) -> "Ring":
+        """demod_ring_create with an arena of the ring's own."""
+        return Ring(self, slots)
+
     # -- helpers ----------------------------------------------------------------
     def synth_fill(self, dst, first_byte: int, seed: int) -> None:
         """Fill a CUDA uint8 tensor with the counter-based synthetic IQ stream."""
@@ -288,3 +292,59 @@ class Demodulator:
         self._check(self._lib.demod_selftest_lane_shift(self._ctx, v.ctypes.data, halo,
                                                         out.ctypes.data), "demod_selftest_lane_shift")
         return out
+
+
+class Ring:
+    """demod_ring_*: the producer/consumer form of the host path (what the backend adapter
+    drives).  put() = demod_ring_input + copy + demod_ring_commit from the producer's thread;
+    take() = demod_ring_collect + copy + demod_ring_release from the consumer's thread."""
+
+    def __init__(self, dem: Demodulator, slots: int | None = None):
+        self._d = dem
+        self._lib = dem._lib
+        self._ring = C.c_void_p()
+        self.chunk = dem.options.buf_size
+        arena = None
+        n = 0
+        if slots is not None:   # a caller-owned pinned arena, as allocateBuffer makes one
+            n = int(slots)
+            arena = C.c_void_p()
+            rc = self._lib.demod_alloc_pinned(C.byref(arena), n * self.chunk)
+            if rc != 0:
+                raise DemodError(f"demod_alloc_pinned failed ({rc})")
+        self._arena = arena
+        dem._check(self._lib.demod_ring_create(dem._ctx, arena, n, C.byref(self._ring)), "demod_ring_create")
+
+    def put(self, data: np.ndarray, final: bool = False) -> None:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = data.size & ~3
+        if n:
+            dst = self._lib.demod_ring_input(self._ring)
+            C.memmove(dst, data.ctypes.data, n)
+        self._d._check(self._lib.demod_ring_commit(self._ring, n, 1 if final else 0), "demod_ring_commit")
+
+    def take(self) -> np.ndarray | None:
+        out = C.c_void_p()
+        n = C.c_uint64(0)
+        self._d._check(self._lib.demod_ring_collect(self._ring, C.byref(out), C.byref(n)), "demod_ring_collect")
+        if not n.value:
+            return None
+        dt = self._d.output_dtype
+        buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(out.value)
+        res = np.frombuffer(buf, dtype=dt).copy()
+        self._d._check(self._lib.demod_ring_release(self._ring), "demod_ring_release")
+        return res
+
+    def close(self) -> None:
+        if self._ring.value:
+            self._lib.demod_ring_destroy(self._ring)
+            self._ring = C.c_void_p()
+        if self._arena is not None and self._arena.value:
+            self._lib.demod_free_pinned(self._arena)
+            self._arena = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMOD_ABI_VERSION 2
+#define DEMOD_ABI_VERSION 3
 
 /* Default chunk size, bytes (include/matrix.h:37-39). */
 #define DEMOD_DEFAULT_BUF_SIZE 262144u
@@ -111,29 +111,62 @@ int demod_last_error_code(const demod_ctx *ctx);
  * passed as void*, NULL = default stream).  d_in must be 16-byte aligned,
  * d_out 16-byte aligned, n_bytes a multiple of 4.  span == NULL means: buffer
  * starts on a chunk boundary and the stream ends with it.
- * One call = one launch of the fused kernel preceded by a small chunk-head
- * launch on the same stream. */
+ * One call = one launch of the fused kernel per 2 GiB of input (the chunk heads are
+ * replayed inside it; for chunks below 128 KiB, more than 4 filter sections or a ragged
+ * stream end, by a small demod_heads launch behind it on the same stream). */
 int demod_process_device(demod_ctx *ctx, const void *d_in, uint64_t n_bytes, void *d_out,
                          const demod_span *span, void *stream);
 
-/* Host-buffer convenience used by the CLI and the backend adapter: uploads
- * h_in in pieces through pinned staging buffers with hipMemcpyAsync on two
- * streams, runs the hot path, downloads to h_out; returns when h_out is
- * complete.  Same span semantics as above (halo is a HOST pointer here). */
+/* HOST-BUFFER PATHS (the reference's main.c:58-98 producer loop and the consumer's
+ * memcpy/fwrite around the per-chunk pipeline, for a device behind PCIe).  All three are
+ * a three-deep pipeline on three HIP streams -- upload, hot path, download -- chained by
+ * events: the upload of piece i+1, the kernels of piece i and the download of piece i-1
+ * overlap.
+ *
+ * demod_process_host: a whole host buffer; returns when h_out is complete.  Caller memory
+ * from demod_alloc_pinned is DMA'd in place; pageable memory is staged through pinned
+ * buffers by a few copy threads.  Same span semantics as above (halo is a HOST pointer). */
 int demod_process_host(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, void *h_out,
                        const demod_span *span);
 
-/* Pipelined form of the host path for a producer/consumer loop (CLI, backend
- * adapter): submit copies n_bytes (<= demod_stream_capacity()) into a pinned
- * staging slot and enqueues upload + hot path + download on that slot's stream,
- * then returns; collect waits for the OLDEST submitted piece and hands out its
- * results (pinned memory owned by the context, valid until the slot is reused
- * two submits later).  Two pieces may be in flight: while piece i is on the
- * GPU the caller can read piece i+1 from its input and write piece i-1 to its
- * output.  submit returns DEMOD_E_INVAL if both slots are still uncollected. */
+/* One hand-off at a time: submit copies n_bytes (<= demod_stream_capacity()) into a pinned
+ * staging stage and enqueues upload + hot path + download, then returns (the caller's
+ * buffer is free again); collect waits for the OLDEST submitted piece and hands out its
+ * results (pinned memory owned by the context, valid until demod_stream_depth() further
+ * submits).  demod_stream_depth() pieces may be in flight; submit returns DEMOD_E_INVAL
+ * when all are. */
 uint64_t demod_stream_capacity(void);
+int demod_stream_depth(void);
 int demod_stream_submit(demod_ctx *ctx, const void *h_in, uint64_t n_bytes, const demod_span *span);
 int demod_stream_collect(demod_ctx *ctx, const void **out, uint64_t *n_outputs);
+
+/* Streaming ring, the producer/consumer form (CLI, backend adapter): hand-offs of one chunk
+ * each are laid one after the other in a pinned ring -- the producer reads its input
+ * straight into the slot demod_ring_input() names, nothing is copied -- and runs of them
+ * travel as ONE upload + ONE hot-path call + ONE download: whatever has arrived while the
+ * GPU was busy (at most 8 MiB), at once when it is idle, so a slow producer's chunks leave
+ * one by one and a fast producer's in batches.
+ *   demod_ring_slots_for(B)  slots a ring for chunk size B wants (0: no ring for this size --
+ *                            below 1 KiB or above the stage capacity; use submit/collect)
+ *   demod_ring_create        pinned_in = NULL: the ring allocates its input arena; else a
+ *                            pinned arena of n_slots * B bytes the caller owns (how
+ *                            allocateBuffer hands the producer its buffer before a context exists)
+ *   demod_ring_input         where the next hand-off goes (blocks while the ring is full)
+ *   demod_ring_commit        n_bytes there are valid: one whole chunk, or -- only with
+ *                            final = 1 -- fewer (multiple of 4; 0 = nothing more); never copies
+ *   demod_ring_collect       results of the oldest batch, in stream order; blocks until they
+ *                            are on the host; *n_outputs = 0 once the stream has ended and
+ *                            everything was handed out
+ *   demod_ring_release       the collected results have been consumed
+ * commit (one thread) and collect/release (another thread) may run concurrently. */
+typedef struct demod_ring demod_ring;
+uint32_t demod_ring_slots_for(uint64_t chunk_bytes);
+int demod_ring_create(demod_ctx *ctx, void *pinned_in, uint32_t n_slots, demod_ring **ring);
+void demod_ring_destroy(demod_ring *ring);
+void *demod_ring_input(demod_ring *ring);
+int demod_ring_commit(demod_ring *ring, uint64_t n_bytes, int final);
+int demod_ring_collect(demod_ring *ring, const void **out, uint64_t *n_outputs);
+int demod_ring_release(demod_ring *ring);
 
 /* Pinned host memory (the reference's allocateBuffer hook,
  * src/matrix.c:282-285 / cuda/matrix.cu:106-109). */
