@@ -89,6 +89,9 @@ struct writer {
     FILE *out;
 };
 
+/* One thread writes: a second one on the same output file does not help -- writes to one
+ * tmpfs/ext4 inode serialise on its lock (tried: two pwrite() halves per batch brought the
+ * /dev/shm file -> file rate DOWN from 2.3 to 1.9 Gsamples/s, tools/host_path_rate.py). */
 static void *write_results(void *p) {
     struct writer *w = p;
     const size_t ob = (size_t) demod_output_bytes(w->dm);

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -412,6 +413,7 @@ struct demod_ring {
     std::vector<Batch> spare;                                // event triples for reuse
     bool lent = false;                                       // the front batch's results are with the caller (collect .. release)
     bool counted = false;                                    // in ctx->rings
+    uint64_t n_batches = 0, n_handoffs = 0, biggest = 0;      // DEMOD_RING_STATS=1: printed when the ring goes
 };
 
 namespace {
@@ -448,6 +450,9 @@ int ring_submit(demod_ring *r, uint32_t count, uint64_t bytes) {
     HIP_TRY(ctx, hipEventRecord(b.downloaded, p->down));
     r->flying.push_back(b);
     r->sent += count;
+    r->n_batches++;
+    r->n_handoffs += count;
+    r->biggest = std::max<uint64_t>(r->biggest, count);
     return DEMOD_OK;
 }
 
@@ -532,6 +537,10 @@ int demod_ring_create(demod_ctx *ctx, void *pinned_in, uint32_t n_slots, demod_r
 
 void demod_ring_destroy(demod_ring *r) {
     if (!r) return;
+    if (const char *e = getenv("DEMOD_RING_STATS"); e && e[0] == '1' && r->n_batches)
+        fprintf(stderr, "demod ring: %llu hand-offs of %llu bytes in %llu batches (%.1f per batch, largest %llu), %u slots\n",
+                (unsigned long long) r->n_handoffs, (unsigned long long) r->slot, (unsigned long long) r->n_batches,
+                (double) r->n_handoffs / (double) r->n_batches, (unsigned long long) r->biggest, r->n_slots);
     (void) hipSetDevice(r->ctx->device);
     for (hipStream_t s : {r->pipe->up, r->pipe->run, r->pipe->down})
         if (s) (void) hipStreamSynchronize(s);

@@ -164,3 +164,25 @@ def test_cli_tiny_chunks_many_handoffs():
         want = oracle.restatement().process(oracle.Flags(**opt.__dict__), data)
         assert got.size == want.size
         check(dm, opt, got, want, data, name=f"cli -b {b}")
+
+
+def test_cli_large_file_to_file_in_batches(tmp_path):
+    """40 MiB + a ragged tail, file in, file out, default chunk: the hand-offs travel through
+    the pinned ring in batches while a second thread writes the results; the bytes are those
+    of one demod_process_host call."""
+    opt = dm.Options(lowpass_in=12500.0, lowpass_out=6500.0)
+    data = oracle.synth_bytes(0x51A, 0, (40 << 20) + 70000)
+    src, dst = tmp_path / "iq.u8", tmp_path / "out.f32"
+    src.write_bytes(data.tobytes())
+    r = subprocess.run([DEMOD, "-i", str(src), "-o", str(dst), "-L", "12500", "-l", "6500"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120, env={**os.environ, "DEMOD_RING_STATS": "1"})
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"demod ring:" in r.stderr and b"161 hand-offs" in r.stderr, r.stderr
+    got = np.fromfile(dst, dtype=np.float32)
+    with dm.Demodulator(opt) as d:
+        want = d.process_host(data)
+    assert got.size == want.size == data.size // 4
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # ... and through a pipe (fwrite) the same
+    out = _run([DEMOD, "-i", str(src), "-o", "-", "-L", "12500", "-l", "6500"], b"")
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint32), want.view(np.uint32))
