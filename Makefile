@@ -27,9 +27,9 @@ all: lib backend cli oracle
 # (oracle is built after backend so that oracle/_ref/demodulator_refhost can link it)
 
 lib: $(PKG)/libdemod_hip.so
-$(PKG)/libdemod_hip.so: $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/host.cpp $(SRC)/plan.cpp $(SRC)/kernels.h \
+$(PKG)/libdemod_hip.so: $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/host.cpp $(SRC)/multi.cpp $(SRC)/plan.cpp $(SRC)/kernels.h \
                         $(SRC)/plan.h $(SRC)/ctx.h include/demod_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/host.cpp $(SRC)/plan.cpp -lpthread
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)/kernels.hip $(SRC)/api.cpp $(SRC)/host.cpp $(SRC)/multi.cpp $(SRC)/plan.cpp -lpthread -ldl
 
 backend: $(PKG)/libdemod_backend.so
 $(PKG)/libdemod_backend.so: $(SRC)/backend.c include/demod_backend.h include/demod_hip.h $(PKG)/libdemod_hip.so

@@ -6,8 +6,8 @@ the work is done by hand-written HIP kernels behind the C ABI of
 include/demod_hip.h.  PyTorch is used only as plumbing (device memory, streams,
 torch.distributed); no compute happens in Python.
 """
-from .demodulator import Demodulator, Options, design, DEFAULT_BUF_SIZE  # noqa: F401
+from .demodulator import Demodulator, MultiDemodulator, Options, Ring, design, plan_shards_c, DEFAULT_BUF_SIZE  # noqa: F401
 from ._native import DemodError, LIB_PATH, HALO_BYTES, ROW_BYTES  # noqa: F401
 
-__all__ = ["Demodulator", "Options", "design", "DemodError", "DEFAULT_BUF_SIZE", "LIB_PATH", "HALO_BYTES",
+__all__ = ["Demodulator", "MultiDemodulator", "Ring", "plan_shards_c", "Options", "design", "DemodError", "DEFAULT_BUF_SIZE", "LIB_PATH", "HALO_BYTES",
            "ROW_BYTES"]

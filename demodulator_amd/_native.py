@@ -30,6 +30,9 @@ EXPORTS = (
     "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_set_head_mode",
     "demod_stream_depth", "demod_ring_slots_for", "demod_ring_create", "demod_ring_destroy", "demod_ring_input",
     "demod_ring_commit", "demod_ring_collect", "demod_ring_release",
+    "demod_plan_shards", "demod_plan_channels", "demod_multi_create", "demod_multi_destroy", "demod_multi_devices",
+    "demod_multi_context", "demod_multi_stream", "demod_multi_plan", "demod_multi_process_device",
+    "demod_multi_synchronize", "demod_multi_halo_transport", "demod_multi_last_error",
 )
 
 
@@ -47,6 +50,14 @@ class Span(C.Structure):
     _fields_ = [
         ("chunk_offset", C.c_uint64), ("halo", C.c_void_p), ("end_of_stream", C.c_uint32),
         ("reserved", C.c_uint32),
+    ]
+
+
+class Shard(C.Structure):
+    """struct demod_shard"""
+    _fields_ = [
+        ("start", C.c_uint64), ("length", C.c_uint64), ("chunk_offset", C.c_uint64), ("needs_halo", C.c_int32),
+        ("end_of_stream", C.c_int32), ("halo_src", C.c_int32), ("halo_dst", C.c_int32),
     ]
 
 
@@ -117,6 +128,18 @@ def load() -> C.CDLL:
         "demod_ring_commit": (i32, [vp, u64, i32]),
         "demod_ring_collect": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "demod_ring_release": (i32, [vp]),
+        "demod_plan_shards": (i32, [u64, i32, u64, u64, u64, C.POINTER(Shard)]),
+        "demod_plan_channels": (i32, [u64, u64, i32, u64, C.POINTER(Shard)]),
+        "demod_multi_create": (i32, [C.POINTER(Params), C.POINTER(i32), i32, C.POINTER(vp)]),
+        "demod_multi_destroy": (None, [vp]),
+        "demod_multi_devices": (i32, [vp]),
+        "demod_multi_context": (vp, [vp, i32]),
+        "demod_multi_stream": (vp, [vp, i32]),
+        "demod_multi_plan": (i32, [vp, u64, u64, C.POINTER(Shard)]),
+        "demod_multi_process_device": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(Shard)]),
+        "demod_multi_synchronize": (i32, [vp]),
+        "demod_multi_halo_transport": (C.c_char_p, [vp]),
+        "demod_multi_last_error": (C.c_char_p, [vp]),
         "demod_design_magnitude_bound": (C.c_double, [C.POINTER(Params)]),
     }
     experiment = bool(os.environ.get("DEMOD_HIP_LIBRARY"))

@@ -348,3 +348,70 @@ class Ring:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def plan_shards_c(total_bytes: int, n: int, chunk_bytes: int, phase_bytes: int = 0, align: int = 0):
+    """demod_plan_shards (the C planner; demodulator_amd.sharding.plan_shards is its Python twin)."""
+    lib = _native.load()
+    arr = (_native.Shard * n)()
+    rc = lib.demod_plan_shards(total_bytes, n, chunk_bytes, phase_bytes, align, arr)
+    if rc != 0:
+        raise DemodError(f"demod_plan_shards failed ({rc})")
+    return list(arr)
+
+
+class MultiDemodulator:
+    """demod_multi_*: one process, several GPUs (one context and stream per device)."""
+
+    def __init__(self, options: Options, devices):
+        self._lib = _native.load()
+        self.options = options
+        self.devices = [int(d) for d in devices]
+        self._m = C.c_void_p()
+        p = options.c_struct()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        rc = self._lib.demod_multi_create(C.byref(p), devs, len(self.devices), C.byref(self._m))
+        if rc != 0:
+            raise DemodError(f"demod_multi_create failed ({rc}): {self._lib.demod_last_error(None).decode()}")
+
+    def plan(self, total_bytes: int, phase_bytes: int = 0):
+        arr = (_native.Shard * len(self.devices))()
+        rc = self._lib.demod_multi_plan(self._m, total_bytes, phase_bytes, arr)
+        if rc != 0:
+            raise DemodError(f"demod_multi_plan failed ({rc})")
+        return arr
+
+    def plan_channels(self, n_channels: int, bytes_per_channel: int):
+        arr = (_native.Shard * len(self.devices))()
+        rc = self._lib.demod_plan_channels(n_channels, bytes_per_channel, len(self.devices), self.options.buf_size, arr)
+        if rc != 0:
+            raise DemodError(f"demod_plan_channels failed ({rc})")
+        return arr
+
+    def process(self, ins, outs, shards) -> None:
+        """ins / outs: one CUDA tensor per device (shard i on device i).  Asynchronous; synchronize() waits."""
+        n = len(self.devices)
+        a = (C.c_void_p * n)(*[t.data_ptr() for t in ins])
+        b = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+        rc = self._lib.demod_multi_process_device(self._m, a, b, shards)
+        if rc != 0:
+            raise DemodError(f"demod_multi_process_device failed ({rc}): {self._lib.demod_multi_last_error(self._m).decode()}")
+
+    def synchronize(self) -> None:
+        if self._lib.demod_multi_synchronize(self._m) != 0:
+            raise DemodError(self._lib.demod_multi_last_error(self._m).decode())
+
+    @property
+    def halo_transport(self) -> str:
+        return self._lib.demod_multi_halo_transport(self._m).decode()
+
+    def close(self) -> None:
+        if self._m.value:
+            self._lib.demod_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

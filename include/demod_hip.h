@@ -168,6 +168,58 @@ int demod_ring_commit(demod_ring *ring, uint64_t n_bytes, int final);
 int demod_ring_collect(demod_ring *ring, const void **out, uint64_t *n_outputs);
 int demod_ring_release(demod_ring *ring);
 
+/* SEVERAL GPUS FROM ONE PROCESS.  The reference has one producer and one consumer thread
+ * and nothing else (src/main.c:67-70); its chunks are filtered independently
+ * (src/matrix.c:272), so a stream splits into contiguous shards, one per device:
+ *   - cuts on chunk boundaries need no exchange at all (BASELINE config 4 as specified);
+ *   - a cut inside a chunk makes the shard on its left need the DEMOD_HALO_BYTES that
+ *     follow it: one ncclSend / ncclRecv pair per cut, grouped, on the devices' streams
+ *     (RCCL over xGMI; librccl is dlopen'ed on first need; without it, or if it refuses the
+ *     device list, the bytes travel with hipMemcpyPeerAsync -- demod_multi_halo_transport()
+ *     returns "rccl", "peer-copy" or "none"; DEMOD_MULTI_TRANSPORT=peer forces the copy);
+ *   - independent channels (BASELINE config 5) are whole-chunk streams of their own: a
+ *     device's channels laid back to back go through one call, no communication.
+ * demod_plan_shards / demod_plan_channels are host-only (no device needed).
+ * Measured on one GPU only (n = 1, and n = 2 on the same device with peer copies): a node
+ * with several MI355X has not been available to this repository's tests. */
+typedef struct demod_shard {
+    uint64_t start;         /* first byte of the shard in the global stream */
+    uint64_t length;        /* bytes (may be 0: fewer rows than devices) */
+    uint64_t chunk_offset;  /* bytes between the enclosing chunk's start and `start` */
+    int32_t needs_halo;     /* the shard ends inside a chunk and bytes follow it in the stream */
+    int32_t end_of_stream;  /* nothing follows this shard */
+    int32_t halo_src;       /* shard that holds the bytes following this one (needs_halo), else -1 */
+    int32_t halo_dst;       /* shard whose look-ahead this shard's first bytes are, else -1 */
+} demod_shard;
+
+/* total_bytes cut into n contiguous shards of (nearly) equal size; the stream itself starts
+ * phase_bytes (multiple of 1024, below the chunk size) into a chunk; cuts are multiples of
+ * `align` bytes (0 = the chunk size when it divides the even share and phase is 0, else
+ * 1 KiB rows).  Empty shards take no part in any exchange. */
+int demod_plan_shards(uint64_t total_bytes, int n, uint64_t chunk_bytes, uint64_t phase_bytes, uint64_t align,
+                      demod_shard *shards);
+/* n_channels independent channels of bytes_per_channel (whole chunks) each, whole channels
+ * per device: shard r = the bytes of device r's channels laid back to back (start counts
+ * from the first channel's first byte). */
+int demod_plan_channels(uint64_t n_channels, uint64_t bytes_per_channel, int n, uint64_t chunk_bytes, demod_shard *shards);
+
+typedef struct demod_multi demod_multi;
+/* One context and one stream per device of the list (a device may not appear twice when
+ * halos travel over RCCL). */
+int demod_multi_create(const demod_params *p, const int *devices, int n_devices, demod_multi **out);
+void demod_multi_destroy(demod_multi *m);
+int demod_multi_devices(const demod_multi *m);
+demod_ctx *demod_multi_context(demod_multi *m, int i);  /* device i's context: allocation, synth_fill, knobs */
+void *demod_multi_stream(demod_multi *m, int i);        /* device i's hipStream_t */
+int demod_multi_plan(const demod_multi *m, uint64_t total_bytes, uint64_t phase_bytes, demod_shard *shards);
+/* One step: d_in[i] / d_out[i] are shard i's buffers in device i's memory.  Exchanges the
+ * halos the plan asks for and enqueues the hot path on every device's stream; returns
+ * without waiting. */
+int demod_multi_process_device(demod_multi *m, void *const *d_in, void *const *d_out, const demod_shard *shards);
+int demod_multi_synchronize(demod_multi *m);
+const char *demod_multi_halo_transport(const demod_multi *m);
+const char *demod_multi_last_error(const demod_multi *m);
+
 /* Pinned host memory (the reference's allocateBuffer hook,
  * src/matrix.c:282-285 / cuda/matrix.cu:106-109). */
 int demod_alloc_pinned(void **p, size_t len);

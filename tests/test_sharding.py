@@ -146,3 +146,24 @@ def test_exchange_probe_that_hangs_is_killed():
     t0 = time.time()
     assert run_probe_child("gloo", 0, 2, 0, _free_port(), 8.0) is False
     assert time.time() - t0 < 60
+
+
+def test_c_planner_equals_python_planner():
+    """demod_plan_shards (multi.cpp, what demod_multi_* uses) and sharding.plan_shards (what
+    bench.py's one-process-per-GPU flow uses) are the same function."""
+    import random
+    import demodulator_amd as dm
+    rnd = random.Random(7)
+    for _ in range(600):
+        B = 1 << rnd.randint(2, 18)
+        world = rnd.randint(1, 9)
+        phase = rnd.randrange(0, max(1, B // 1024)) * 1024 if B >= 1024 else 0
+        total = rnd.randrange(0, 40 * B + 5000)
+        align = rnd.choice([0, 0, 1024, B]) if B >= 1024 else 0
+        py = plan_shards(total, world, B, phase_bytes=phase, align=(align or None))
+        c = dm.plan_shards_c(total, world, B, phase, align)
+        for a, b in zip(py, c):
+            assert (a.start, a.length, a.chunk_offset, int(a.needs_halo), int(a.end_of_stream), a.halo_src, a.halo_dst) == \
+                   (b.start, b.length, b.chunk_offset, b.needs_halo, b.end_of_stream, b.halo_src, b.halo_dst), (B, world, phase, total)
+    with pytest.raises(dm.DemodError):
+        dm.plan_shards_c(1 << 20, 2, 16384, 100)          # phase not a multiple of 1024

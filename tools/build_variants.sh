@@ -8,7 +8,7 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize 
 mkdir -p demodulator_amd/variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  ( /opt/rocm/bin/hipcc $BASE $flags -o demodulator_amd/variants/libdemod_hip_$name.so $SRC/kernels.hip $SRC/api.cpp $SRC/host.cpp $SRC/plan.cpp 2>&1 | grep -E "error" || true ) &
+  ( /opt/rocm/bin/hipcc $BASE $flags -o demodulator_amd/variants/libdemod_hip_$name.so $SRC/kernels.hip $SRC/api.cpp $SRC/host.cpp $SRC/multi.cpp $SRC/plan.cpp -lpthread -ldl 2>&1 | grep -E "error" || true ) &
 done
 wait
 ls demodulator_amd/variants/
