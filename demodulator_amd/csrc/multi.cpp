@@ -244,7 +244,8 @@ int demod_multi_process_device(demod_multi *m, void *const *d_in, void *const *d
             any_halo = true;
         }
     }
-    if (any_halo && m->transport == demod_multi::kUnset) choose_transport(m);
+    // "none" only says that no step has needed an exchange so far
+    if (any_halo && (m->transport == demod_multi::kUnset || m->transport == demod_multi::kNone)) choose_transport(m);
     if (!any_halo && m->transport == demod_multi::kUnset) m->transport = demod_multi::kNone;
 
     // ---- look-ahead bytes of every cut that falls inside a chunk --------------------------
