@@ -40,6 +40,14 @@ namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Packed f32: two independent values in an aligned register pair, one v_pk_mul_f32 /
+// v_pk_fma_f32 for both -- per element the very operations (and roundings) of the scalar
+// forms.  Used where the data comes in pairs by nature: (re, im) of a sample, and two
+// neighbouring outputs through the atan2 polynomial.  A quarter fewer VALU instructions
+// per row; the SLP vectoriser stays off (it pairs values that are not adjacent and pays
+// for it in moves).
+typedef float pf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pf2 fma2(pf2 a, pf2 b, pf2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 #define DEMOD_LOAD_POLICY " nt"   // cache policy suffix of the streaming loads: every byte is read once
 #ifndef DEMOD_WAVES_PER_BLOCK
@@ -124,6 +132,43 @@ __device__ __forceinline__ float fast_atan2(float y, float x, float lead = kAtan
     r = fabsf(r) - __uint_as_float(xneg & 0x40490FDBu);
     // magnitude of r, sign of y
     return __uint_as_float(bit_select(0x7FFFFFFFu, __float_as_uint(r), yb));
+}
+
+// Two atan2 at once: the octant logic per element as in fast_atan2, the polynomial on the
+// pair (v_pk_mul_f32 / v_pk_fma_f32: the same operations on the same values).
+__device__ __forceinline__ void fast_atan2_pair(float y0, float x0, float y1, float x1, float lead, float &r0, float &r1) {
+    const uint32_t xb0 = __float_as_uint(x0), yb0 = __float_as_uint(y0), xb1 = __float_as_uint(x1), yb1 = __float_as_uint(y1);
+    const float t0 = fabsf(x0) - fabsf(y0), t1 = fabsf(x1) - fabsf(y1);
+    const uint32_t sw0 = (uint32_t) (__float_as_int(t0) >> 31), sw1 = (uint32_t) (__float_as_int(t1) >> 31);
+    const float hi0 = fabsf(__uint_as_float(bit_select(sw0, yb0, xb0))), lo0 = fabsf(__uint_as_float(bit_select(sw0, xb0, yb0)));
+    const float hi1 = fabsf(__uint_as_float(bit_select(sw1, yb1, xb1))), lo1 = fabsf(__uint_as_float(bit_select(sw1, xb1, yb1)));
+    const pf2 q = {fmul_legacy(lo0, __builtin_amdgcn_rcpf(hi0)), fmul_legacy(lo1, __builtin_amdgcn_rcpf(hi1))};
+    const pf2 s = q * q;
+    auto k = [](float c) { return pf2{c, c}; };
+    pf2 p = fma2(k(lead), s, k(2.186295763e-02f));
+    p = fma2(p, s, k(-5.591232702e-02f));
+    p = fma2(p, s, k(9.642197192e-02f));
+    p = fma2(p, s, k(-1.390862912e-01f));
+    p = fma2(p, s, k(1.994656622e-01f));
+    p = fma2(p, s, k(-3.332985938e-01f));
+    p = fma2(p, s, k(9.999993443e-01f));
+    const pf2 r = fma2(p, q, pf2{__uint_as_float(sw0 & 0xBFC90FDBu), __uint_as_float(sw1 & 0xBFC90FDBu)});
+    const uint32_t xn0 = (uint32_t) ((int32_t) xb0 >> 31), xn1 = (uint32_t) ((int32_t) xb1 >> 31);
+    const float a0 = fabsf(r.x) - __uint_as_float(xn0 & 0x40490FDBu), a1 = fabsf(r.y) - __uint_as_float(xn1 & 0x40490FDBu);
+    r0 = __uint_as_float(bit_select(0x7FFFFFFFu, __float_as_uint(a0), yb0));
+    r1 = __uint_as_float(bit_select(0x7FFFFFFFu, __float_as_uint(a1), yb1));
+}
+
+// The discriminator's argument for complex samples z0 = (a, b), z1 = (c, d), as the pair
+// (zr, zj) = (b d + a c, b c + (-a) d): the two products of a first, then one fused
+// multiply-add per lane -- operation for operation what discriminate() does.  The operand
+// selectors pick the lanes (op_sel: low half source, op_sel_hi: high half source), neg_hi
+// flips the sign of a d on its way into the sum [-(a d) == (-a) d bit for bit].
+__device__ __forceinline__ pf2 discriminator_argument(pf2 z0, pf2 z1) {
+    pf2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(z0), "v"(z1));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(z0), "v"(z1), "v"(t));
+    return r;
 }
 
 // Quadrature discriminator of one pair of complex samples z0 = a + ib,
@@ -333,9 +378,31 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
     }
 
     float d[ND];
-    if constexpr (TIN > 0) {
-        // complex samples 8.. come from the next lane
-        if constexpr (TIN > 1) ex.template next_x<TIN - 1>(xr, xi);
+    // complex samples 8.. come from the next lane
+    if constexpr (TIN > 1) ex.template next_x<TIN - 1>(xr, xi);
+    if constexpr (!RAGGED) {
+        // the streaming build works on (re, im) pairs
+        pf2 z[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if constexpr (TIN == 0) {
+                z[k] = pf2{xr[k], xi[k]};
+            } else if constexpr (FOLD) {
+                pf2 acc = fma2(pf2{a.hin[0], a.hin[0]}, pf2{xr[k], xi[k]}, pf2{a.fold_re, a.fold_im});
+#pragma unroll
+                for (int j = 1; j < TIN; ++j) acc = fma2(pf2{a.hin[j], a.hin[j]}, pf2{xr[k + j], xi[k + j]}, acc);
+                z[k] = acc;
+            } else {
+                // the real lane starts with a product, the imaginary lane with the bias: not a pair
+                z[k] = pf2{stencil0<TIN>(a.hin, &xr[k]), stencil<TIN>(a.hin, &xi[k], a.bias_im)};
+            }
+        }
+        pf2 arg[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) arg[j] = discriminator_argument(z[2 * j], z[2 * j + 1]);
+        fast_atan2_pair(arg[0].y, arg[0].x, arg[1].y, arg[1].x, lead, d[0], d[1]);
+        fast_atan2_pair(arg[2].y, arg[2].x, arg[3].y, arg[3].x, lead, d[2], d[3]);
+    } else if constexpr (TIN > 0) {
         float zr[8], zi[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -582,7 +649,8 @@ __device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *ch
 #define DEMOD_MIN_WAVES_PER_SIMD 8
 #endif
 template <int TIN, int TOUT, int COND, bool RAGGED, bool S16>
-__global__ __launch_bounds__(64 * kWavesPerBlock, DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
+// (the int16 store needs a few registers more: 7 wavefronts per SIMD rather than spills)
+__global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD - 1 : DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if DEMOD_XCD_INTERLEAVE
