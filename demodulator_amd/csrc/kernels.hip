@@ -49,9 +49,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float pf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pf2 fma2(pf2 a, pf2 b, pf2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+#ifndef DEMOD_LOAD_POLICY
 #define DEMOD_LOAD_POLICY " nt"   // cache policy suffix of the streaming loads: every byte is read once
+#endif
+// 4 independent wavefronts per workgroup: +0.5-0.8 % over 8 on two boxes after the packed-f32
+// diet (2, 1: -3 %), profiles/r2_ab_workgroup.txt
 #ifndef DEMOD_WAVES_PER_BLOCK
-#define DEMOD_WAVES_PER_BLOCK 8
+#define DEMOD_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = DEMOD_WAVES_PER_BLOCK;  // independent wavefronts per workgroup of demod_rows
 // Workgroups are handed to the 8 XCDs round-robin.  With 8, the workgroups of a group of
