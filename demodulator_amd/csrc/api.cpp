@@ -24,7 +24,7 @@ constexpr uint32_t kTinyThreads = 8192;
 constexpr uint32_t kPieceRows = 1u << 21;       // rows per demod_rows launch (2 GiB of input)
 // chunk heads inside the streaming kernel for chunks of at least this many rows (below, the
 // demod_heads kernel is cheaper), see heads_are_fused()
-constexpr uint64_t kFusedMinRows = 128;
+constexpr uint64_t kFusedMinRows = 256;
 
 uint32_t log2u(uint64_t v) {
     uint32_t l = 0;
@@ -212,10 +212,10 @@ double demod_kernel_ms(demod_ctx *ctx, int *launches) {
 // a head costs that wavefront about a third of a 4-row segment's arithmetic (~270 VALU
 // instructions with a quarter of the lanes busy), against ONE THREAD of the demod_heads kernel
 // (64 heads per wavefront, but a launch of its own).  Measured on MI355X (tools/chunk_sweep.py,
-// tools/head_mode_probe.py, profiles/r2_head_modes.txt): level from 128 KiB chunks up (one
-// kernel per dispatch, the default chunk size included), the separate kernel ahead below
-// that (64 KiB: 0.743 against 0.731 of peak, 16 KiB: 0.730 against 0.672, 1 KiB: 0.37
-// against 0.27).
+// tools/head_mode_probe.py, profiles/r2_head_modes.txt): level at the default 256 KiB
+// chunks and above (one kernel per dispatch), the separate kernel ahead below that (128 KiB:
+// box-dependent, 64 KiB: 0.743 against 0.731 of peak, 16 KiB: 0.730 against 0.672, 1 KiB:
+// 0.37 against 0.27).
 static bool heads_are_fused(const demod_ctx *ctx) {
     const Plan &pl = ctx->plan;
     if (pl.head_quads == 0) return true;

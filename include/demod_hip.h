@@ -112,7 +112,7 @@ int demod_last_error_code(const demod_ctx *ctx);
  * d_out 16-byte aligned, n_bytes a multiple of 4.  span == NULL means: buffer
  * starts on a chunk boundary and the stream ends with it.
  * One call = one launch of the fused kernel per 2 GiB of input (the chunk heads are
- * replayed inside it; for chunks below 128 KiB, more than 4 filter sections or a ragged
+ * replayed inside it; for chunks below 256 KiB, more than 4 filter sections or a ragged
  * stream end, by a small demod_heads launch behind it on the same stream). */
 int demod_process_device(demod_ctx *ctx, const void *d_in, uint64_t n_bytes, void *d_out,
                          const demod_span *span, void *stream);
