@@ -160,7 +160,9 @@ def run_probe_child(backend: str, rank: int, world: int, local_rank: int, port: 
     import subprocess
     import sys
 
-    env = dict(os.environ)
+    # a rendezvous of its own: under torch.distributed.run the parent's environment says "use the
+    # elastic agent's store" (TORCHELASTIC_USE_AGENT_STORE), which only exists on the parent's port
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                LOCAL_RANK=str(local_rank))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

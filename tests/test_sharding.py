@@ -167,3 +167,19 @@ def test_c_planner_equals_python_planner():
                    (b.start, b.length, b.chunk_offset, b.needs_halo, b.end_of_stream, b.halo_src, b.halo_dst), (B, world, phase, total)
     with pytest.raises(dm.DemodError):
         dm.plan_shards_c(1 << 20, 2, 16384, 100)          # phase not a multiple of 1024
+
+
+def test_probe_under_torch_distributed_run():
+    """bench.py's probe sequence started the way the driver starts it: under
+    torch.distributed.run the environment tells env:// rendezvous to use the elastic agent's
+    store, which does not exist on the probe's own port -- the probe child must not inherit
+    that (it would wait for a store nobody serves and the run would end as "halo_exchange":
+    "failed")."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(here, "_probe_under_launcher.py")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"PROBE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
