@@ -54,3 +54,23 @@ def test_a_failed_halo_probe_is_not_a_pass():
     assert rc != 0 and line is not None, err
     assert line["halo_exchange"] == "failed" and line["n_gpus"] == 2
     assert "chunk-aligned cuts, no exchange" in line["config"]["sharding"] and "FAILED" in line["config"]["sharding"]
+
+
+def test_two_ranks_under_torch_distributed_run_as_the_driver_launches_them():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...`: the ranks find RANK / WORLD_SIZE in the environment,
+    do not self-launch, and the probe's child processes keep a rendezvous of their own although
+    the launcher's environment points at the elastic agent's store."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, DEMOD_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2",
+                        "--workload", "c3", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=e)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["halo_exchange"].startswith("gloo send/recv") and line["value"] > 0
