@@ -423,7 +423,7 @@ def test_random_option_sets_and_lengths(orc):
         # an accepted design is PROVEN finite from its coefficients (plan_magnitude_bound), for the
         # reference's arithmetic as for this path's: the reference's NaN -> 0 rule (src/matrix.c:174)
         # never fires, and there is nothing to skip
-        assert np.all(np.isfinite(want)) and float(np.abs(want).max()) <= design["magnitude_bound"], opt
+        assert np.all(np.isfinite(want)) and float(np.abs(want).max(initial=0.0)) <= design["magnitude_bound"], opt
         _check(f"{opt} n_bytes={n_bytes}", got, want, opt, data)
         n_cases += 1
     assert n_cases >= min(30, rounds // 2)
