@@ -146,9 +146,9 @@ class _Lib:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         out = np.zeros(data.size // 4 + 4, dtype=np.float32)
         p = flags.c_struct()
-        if self.prefix == "ref" and ((flags.mode >> 2) & 3) == 2:
-            # -q2: the reference keeps static state sized by its first call, so
-            # every stream gets a process of its own (oracle/ref_stream_main.c)
+        if self.prefix == "ref" and ((flags.mode >> 2) & 3) in (1, 2):
+            # -q1 / -q2: the reference keeps static state (running offsets; a buffer sized by
+            # its first call), so every stream gets a process of its own (oracle/ref_stream_main.c)
             exe = os.path.join(os.path.dirname(self.path), "ref_stream")
             msg = bytes(p) + np.uint64(data.size).tobytes() + data.tobytes()
             r = subprocess.run([exe], input=msg, stdout=subprocess.PIPE, check=False)

@@ -198,6 +198,25 @@ void orc_unpack_normalize(const uint8_t *bytes, size_t len, float *out) {
     for (i = 0; i < len; ++i) out[i] = (float) bytes[i] * denom - 1.;
 }
 
+void orc_unpack_correct_iq(const uint8_t *bytes, size_t len, float *out, float esr, float off[2]) {
+    /* correctIq, src/matrix.c:120-140: a two-ended loop -- iteration i/2 takes the complex
+     * sample at bytes i, i+1 and its mirror image at len-i-2, len-i-1, subtracts the running
+     * offsets from both and moves the offsets by (sum of the two corrected values) * esr.
+     * `off` is the reference's static off[2]: it carries over from chunk to chunk. */
+    const size_t N = len >> 1;
+    size_t i;
+    for (i = 0; i < N; i += 2) {
+        out[i] = ((float) bytes[i]) - off[0];
+        out[len - i - 2] = ((float) bytes[len - i - 2]) - off[0];
+
+        out[i + 1] = ((float) bytes[i + 1]) - off[1];
+        out[len - i - 1] = ((float) bytes[len - i - 1]) - off[1];
+
+        off[0] += (out[i] + out[len - i - 2]) * esr;
+        off[1] += (out[i + 1] + out[len - i - 1]) * esr;
+    }
+}
+
 void orc_discriminate(const float *in, size_t len, float *out) {
     /* src/matrix.c:166-175 */
     size_t i;
@@ -252,6 +271,8 @@ typedef struct {
     int prefilter;          /* complex input filter enabled */
     int normalize;          /* -q3 unpack instead of shiftOrigin */
     int highpass;           /* -q2: highpassDc in front of everything else */
+    int correct;            /* -q1: correctIq, offsets carried from chunk to chunk */
+    float esr;              /* src/matrix.c:210 */
     float (*sos_in)[6];
     float (*sos_out)[6];
     float sos_hp[2][6];     /* src/matrix.c:147,151 */
@@ -264,7 +285,6 @@ static int make_plan(const orc_params *p, plan_t *pl) {
 
     memset(pl, 0, sizeof *pl);
     if (!demod_mode) return -1;            /* src/matrix.c:244-251, unreachable from the CLI */
-    if (iq_mode == 1) return -1;           /* correctIq: state carried across chunks, out of scope */
     if (!p->out_degree || !p->buf_size || (p->buf_size & 3)) return -1;
     /* src/matrix.c:190-192 */
     if (p->lowpass_in != 0 && !in_degree) in_degree = p->out_degree;
@@ -275,6 +295,8 @@ static int make_plan(const orc_params *p, plan_t *pl) {
     pl->chunk = p->buf_size;
     pl->normalize = (iq_mode == 3);
     pl->highpass = (iq_mode == 2);
+    pl->correct = (iq_mode == 1);
+    pl->esr = (float) (50. / p->sample_rate); /* src/matrix.c:210 */
     /* src/matrix.c:151: Butterworth highpass, degree 3, 1 Hz, epsilon 0 */
     if (pl->highpass) orc_design_sos(2, 3, 1.L, p->sample_rate, 0.L, pl->sos_hp);
     pl->prefilter = in_degree != 0;
@@ -328,7 +350,7 @@ static void free_scratch(scratch_t *s) {
  * (len == B for full chunks; shorter only for the build's tail policy, where
  * the buffers keep their full-chunk size and offsets as the reference's do). */
 static void run_chunk(const plan_t *pl, scratch_t *s, const uint8_t *bytes, size_t len,
-                      float *out) {
+                      float *out, float off[2]) {
     float *F = s->work;
     const size_t B = len;
     const size_t n_out = B >> 2;
@@ -342,7 +364,9 @@ static void run_chunk(const plan_t *pl, scratch_t *s, const uint8_t *bytes, size
         orc_unpack_shift(bytes, B, s->hp);
         memset(s->hp + B, 0, (pl->chunk + HP_PAD - B) * sizeof(float));
         orc_filter_complex(s->hp, F, B, 2, (const float(*)[6]) pl->sos_hp);
-    } else if (pl->normalize)
+    } else if (pl->correct)
+        orc_unpack_correct_iq(bytes, B, F, pl->esr, off);
+    else if (pl->normalize)
         orc_unpack_normalize(bytes, B, F);
     else
         orc_unpack_shift(bytes, B, F);
@@ -374,6 +398,7 @@ typedef struct {
     const uint8_t *in;
     float *out;
     size_t first, last; /* chunk range [first, last) */
+    float off[2];       /* -q1: the offsets chunk `first` starts from */
 } job_t;
 
 static void *worker(void *arg) {
@@ -383,9 +408,26 @@ static void *worker(void *arg) {
     if (make_scratch(j->pl, &s)) return (void *) 1;
     for (c = j->first; c < j->last; ++c)
         run_chunk(j->pl, &s, j->in + c * j->pl->chunk, j->pl->chunk,
-                  j->out + c * (j->pl->chunk >> 2));
+                  j->out + c * (j->pl->chunk >> 2), j->off);
     free_scratch(&s);
     return NULL;
+}
+
+/* -q1: the offsets after the first `chunks` chunks (the recurrence of correctIq alone,
+ * src/matrix.c:131-138, without storing the corrected samples) -- what lets the
+ * chunk-parallel form start every worker from the state the serial loop would hand it. */
+static void correct_iq_state(const plan_t *pl, const uint8_t *in, size_t first, size_t last, float off[2]) {
+    const size_t len = pl->chunk, N = len >> 1;
+    size_t c, i;
+    for (c = first; c < last; ++c) {
+        const uint8_t *b = in + c * len;
+        for (i = 0; i < N; i += 2) {
+            const float f0 = ((float) b[i]) - off[0], m0 = ((float) b[len - i - 2]) - off[0];
+            const float f1 = ((float) b[i + 1]) - off[1], m1 = ((float) b[len - i - 1]) - off[1];
+            off[0] += (f0 + m0) * pl->esr;
+            off[1] += (f1 + m1) * pl->esr;
+        }
+    }
 }
 
 long long orc_process_stream_mt(const orc_params *p, const uint8_t *in, size_t n_bytes,
@@ -400,9 +442,12 @@ long long orc_process_stream_mt(const orc_params *p, const uint8_t *in, size_t n
     if (threads < 1) threads = 1;
     if ((size_t) threads > full) threads = full ? (int) full : 1;
 
+    float off[2] = {0.f, 0.f}; /* static REAL off[2] = {}, src/matrix.c:125 */
     if (threads == 1) {
-        job_t j = {&pl, in, out, 0, full};
+        job_t j = {&pl, in, out, 0, full, {0.f, 0.f}};
         if (worker(&j)) { free_plan(&pl); return -1; }
+        off[0] = j.off[0];
+        off[1] = j.off[1];
     } else {
         pthread_t *tid = calloc(threads, sizeof *tid);
         job_t *jobs = calloc(threads, sizeof *jobs);
@@ -412,6 +457,9 @@ long long orc_process_stream_mt(const orc_params *p, const uint8_t *in, size_t n
             jobs[t].out = out;
             jobs[t].first = full * t / threads;
             jobs[t].last = full * (t + 1) / threads;
+            jobs[t].off[0] = off[0];
+            jobs[t].off[1] = off[1];
+            if (pl.correct) correct_iq_state(&pl, in, jobs[t].first, jobs[t].last, off);
             pthread_create(&tid[t], NULL, worker, &jobs[t]);
         }
         for (t = 0; t < (size_t) threads; ++t) pthread_join(tid[t], NULL);
@@ -423,7 +471,7 @@ long long orc_process_stream_mt(const orc_params *p, const uint8_t *in, size_t n
     if (tail) {
         scratch_t s;
         if (make_scratch(&pl, &s)) { free_plan(&pl); return -1; }
-        run_chunk(&pl, &s, in + full * pl.chunk, tail, out + written);
+        run_chunk(&pl, &s, in + full * pl.chunk, tail, out + written, off);
         free_scratch(&s);
         written += (long long) (tail >> 2);
     }

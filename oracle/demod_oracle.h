@@ -55,6 +55,11 @@ void orc_unpack_shift(const uint8_t *bytes, size_t len, float *out);
 /* uint8 IQ -> float, byte*(2/255)-1; normalizeInput, src/matrix.c:100-118. */
 void orc_unpack_normalize(const uint8_t *bytes, size_t len, float *out);
 
+/* uint8 IQ -> float with running DC offsets, correctIq (-q1), src/matrix.c:120-140;
+ * esr = (float)(50 / sample_rate) (src/matrix.c:210); off[2] is the reference's static
+ * state, carried from call to call. */
+void orc_unpack_correct_iq(const uint8_t *bytes, size_t len, float *out, float esr, float off[2]);
+
 /* Quadrature discriminator, fmDemod, src/matrix.c:159-176. len = floats in. */
 void orc_discriminate(const float *in, size_t len, float *out);
 
@@ -71,7 +76,7 @@ void orc_filter_complex(const float *x, float *y, size_t len, size_t sections,
  * is replayed as a short chunk of (r & ~3) bytes yielding r/4 floats (the
  * build's deterministic tail policy; the reference's
  * own tail is racy).  Returns the number of floats written, or -1 on an
- * unsupported option set (-D without -L, -q1/-q2, demod mode 0). */
+ * unsupported option set (-D without -L, demod mode 0). */
 long long orc_process_stream(const orc_params *p, const uint8_t *in, size_t n_bytes,
                              float *out);
 

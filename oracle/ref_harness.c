@@ -46,7 +46,8 @@ void ref_filter_complex(float *x, float *y, size_t len, size_t sections,
  * sequence, the reference's own functions.  Full chunks only (the reference's
  * tail handling is racy).  Returns floats written or
  * -1 for option sets the harness does not drive. */
-/* -q2 in THIS function is only meaningful in a fresh process: highpassDc keeps
+/* -q1 and -q2 in THIS function are only meaningful in a fresh process (-q1: correctIq's
+ * static offsets start at zero once per process, src/matrix.c:125).  -q2: highpassDc keeps
  * a static buffer sized by its first call and static coefficients
  * (src/matrix.c:147-153), and what its filter reads behind that buffer depends
  * on the allocator's state.  oracle/__init__.py therefore runs -q2 streams
@@ -66,10 +67,11 @@ long long ref_process_stream(const orc_params *p, const uint8_t *in, size_t n_by
     float *work, *dem;
     size_t c;
 
-    if (!demodMode || iqMode == 1) return -1;
+    if (!demodMode) return -1;
     if (inDegree && p->lowpass_in == 0) return -1;
-    unpack = iqMode == 3 ? normalizeInput : iqMode == 2 ? highpassDc : shiftOrigin;
+    unpack = iqMode == 3 ? normalizeInput : iqMode == 2 ? highpassDc : iqMode == 1 ? correctIq : shiftOrigin;
     samplingRate = p->sample_rate;  /* src/matrix.c:206 */
+    esr = (REAL) (50. / p->sample_rate); /* src/matrix.c:210 (correctIq keeps static offsets: one process per stream) */
 
     {
         REAL sosIn[sosLenIn ? sosLenIn : 1][6];

@@ -81,6 +81,16 @@ STREAM_CASES["q2_d5_S96k_b65536"] = (flagset(mode=0x18, sample_rate=96000.0, out
 STREAM_CASES["q2_L_b32768"] = (flagset(mode=0x18, lowpass_in=12500.0, lowpass_out=6500.0,
                                        buf_size=32768), 0xD3300D52, 2)
 
+# -q1 correctIq conditioning (src/matrix.c:120-140): running DC offsets, carried from chunk to
+# chunk (static state: the reference runs each stream in a process of its own).  Small chunks
+# are the interesting ones: there the state a chunk starts from decides its results.
+STREAM_CASES["q1_b32768"] = (flagset(mode=0x14, buf_size=32768), 0xD3300D60, 4)
+STREAM_CASES["q1_L_b16384"] = (flagset(mode=0x14, lowpass_in=12500.0, lowpass_out=6500.0,
+                                       buf_size=16384), 0xD3300D61, 4)
+STREAM_CASES["q1_b1024"] = (flagset(mode=0x14, buf_size=1024), 0xD3300D62, 16)
+STREAM_CASES["q1_S96k_d5_b4096"] = (flagset(mode=0x14, sample_rate=96000.0, out_degree=5,
+                                            buf_size=4096), 0xD3300D63, 6)
+
 # known-answer byte quads, SURVEY.md Appendix A.2 (signed zeros, +-pi, wrap of 255)
 QUADS = np.array([
     [127, 127, 122, 124], [127, 127, 132, 130], [127, 127, 127, 127], [127, 130, 127, 120],

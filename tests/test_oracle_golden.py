@@ -90,7 +90,7 @@ def test_rejects_undefined_option_sets(orc):
     with pytest.raises(ValueError):
         orc.process(oracle.Flags(in_degree=3, buf_size=4096), data)      # -D without -L
     with pytest.raises(ValueError):
-        orc.process(oracle.Flags(mode=0x14, buf_size=4096), data)        # -q1 correctIq
+        orc.process(oracle.Flags(mode=0x00, buf_size=4096), data)        # demod mode 0
 
 
 def test_against_live_reference(orc):
@@ -106,6 +106,14 @@ def test_against_live_reference(orc):
                           buf_size=int(1 << rng.integers(5, 14)))
         data = rng.integers(0, 256, fl.buf_size * 3, dtype=np.uint8)
         assert np.array_equal(bits(orc.process(fl, data)), bits(ref.process(fl, data))), fl
+    # -q1 correctIq: static offsets carried from chunk to chunk; one reference process per stream
+    for kw in (dict(buf_size=1 << 10), dict(buf_size=1 << 15, lowpass_in=12500.0, lowpass_out=6500.0),
+               dict(buf_size=1 << 6, sample_rate=96000.0, out_degree=2)):
+        fl = oracle.Flags(mode=0x14, **kw)
+        data = rng.integers(0, 256, fl.buf_size * 7, dtype=np.uint8)
+        a = orc.process(fl, data)
+        assert np.array_equal(bits(a), bits(ref.process(fl, data))), fl
+        assert np.array_equal(bits(a), bits(orc.process(fl, data, threads=3))), fl   # the chunk-parallel form
     # -q2 highpassDc, alone and in front of -L; chunks of 32 KiB and more (below that the
     # reference reads heap contents behind its buffer); one reference process per stream
     for kw in (dict(), dict(lowpass_in=12500.0, lowpass_out=6500.0), dict(out_degree=6, sample_rate=96000.0)):
