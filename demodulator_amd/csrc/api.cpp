@@ -113,6 +113,8 @@ void demod_destroy(demod_ctx *ctx) {
         (void) hipEventDestroy(p.first);
         (void) hipEventDestroy(p.second);
     }
+    if (ctx->q1_table) (void) hipFree(ctx->q1_table);
+    if (ctx->q1_carry) (void) hipFree(ctx->q1_carry);
     if (ctx->tiny_work) (void) hipFree(ctx->tiny_work);
     if (ctx->tiny_done) (void) hipEventDestroy(ctx->tiny_done);
     delete ctx;
@@ -218,6 +220,7 @@ double demod_kernel_ms(demod_ctx *ctx, int *launches) {
 // 0.37 against 0.27).
 static bool heads_are_fused(const demod_ctx *ctx) {
     const Plan &pl = ctx->plan;
+    if (pl.conditioning == kCorrectIq) return false;  // -q1 runs in the bounds-checked build
     if (pl.head_quads == 0) return true;
     const bool can = pl.in.sections <= kFusedHeadSections && pl.out.sections <= kFusedHeadSections && pl.pre.sections == 0;
     if (!can || ctx->head_mode == 0) return false;
@@ -265,8 +268,48 @@ static void fill_sections(const Plan &pl, int &sec_in, int &sec_out, float (*sos
     scale = (float) (2. / 255.);
 }
 
+// -q1: replay correctIq's offsets for the n_bytes at d_in (whole chunks of B bytes and, at a
+// stream end, a short last one) into ctx->q1_table, starting from the state the previous call
+// left (src/matrix.c:125: static, zero at process start).
+static int run_offsets(demod_ctx *ctx, const uint8_t *d_in, uint64_t n_bytes, uint64_t B, hipStream_t stream) {
+    const Plan &pl = ctx->plan;
+    const uint64_t pairs = n_bytes / 4 + 4;
+    if (!ctx->q1_carry) {
+        HIP_TRY(ctx, hipMalloc((void **) &ctx->q1_carry, 4 * sizeof(float)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->q1_carry, 0, 4 * sizeof(float), stream));
+    }
+    if (ctx->q1_pairs < pairs) {
+        if (ctx->q1_table) {
+            HIP_TRY(ctx, hipDeviceSynchronize());  // an earlier call's kernels may still read it
+            HIP_TRY(ctx, hipFree(ctx->q1_table));
+        }
+        ctx->q1_table = nullptr;
+        ctx->q1_pairs = 0;
+        HIP_TRY(ctx, hipMalloc((void **) &ctx->q1_table, pairs * 2 * sizeof(float)));
+        ctx->q1_pairs = pairs;
+    }
+    OffsetLaunch o{};
+    o.in = d_in;
+    o.table = ctx->q1_table;
+    o.carry_in = ctx->q1_carry + 2 * ctx->q1_flip;
+    o.carry_out = ctx->q1_carry + 2 * (ctx->q1_flip ^ 1);
+    ctx->q1_flip ^= 1;
+    o.chunk_bytes = B;
+    o.n_chunks = n_bytes / B;
+    o.tail_bytes = (uint32_t) (n_bytes - o.n_chunks * B);
+    o.stride = (uint32_t) (B / 4);
+    o.warm = pl.q1_warm;
+    o.esr = pl.esr;
+    if (launch_offsets(o, stream)) {
+        ctx->fail(DEMOD_E_HIP, "correct_iq_offsets launch", hipGetLastError());
+        return DEMOD_E_HIP;
+    }
+    return DEMOD_OK;
+}
+
 static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, uint64_t n_chunks,
-                    uint32_t tail_bytes, void *d_out, hipStream_t stream) {
+                    uint32_t tail_bytes, void *d_out, hipStream_t stream, const float *q1_table = nullptr,
+                    uint32_t q1_stride = 0) {
     const Plan &pl = ctx->plan;
     const uint64_t stride = 6 * chunk_bytes + 3 * (4 * kMaxSections + 8);
     if (!ctx->tiny_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tiny_done, hipEventDisableTiming));
@@ -294,6 +337,8 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     t.in_separate = pl.in_separate;
     t.out_s16 = ctx->out_s16;
     t.out_scale = ctx->out_scale;
+    t.q1_table = q1_table;
+    t.q1_stride = q1_stride;
     const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
     const uint32_t threads = (uint32_t) std::min<uint64_t>(total, kTinyThreads);
     if (launch_tiny(t, pl.conditioning, threads, stream)) {
@@ -334,6 +379,20 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     }
     const uint8_t *halo = span ? static_cast<const uint8_t *>(span->halo) : nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // -q1: correctIq's offsets run through the whole stream (static state, src/matrix.c:125), chunk
+    // after chunk, call after call: buffers are whole chunks from a chunk boundary (a short last
+    // one ends the stream), handed over in stream order on one HIP stream
+    const bool q1 = pl.conditioning == kCorrectIq;
+    if (q1) {
+        if (ctx->seamless || offset != 0 || ((n_bytes % B) != 0 && !eos)) {
+            ctx->fail(DEMOD_E_INVAL, "-q1 (correctIq) carries its offsets from chunk to chunk: a buffer must start on a chunk "
+                                     "boundary and hold whole chunks (a short last chunk ends the stream); no seamless mode");
+            return DEMOD_E_INVAL;
+        }
+        const int rc = run_offsets(ctx, d_in, n_bytes, B, stream);
+        if (rc) return rc;
+    }
+    const uint32_t q1_stride = (uint32_t) (B / 4);
 
     // ---- chunks shorter than one row: literal whole-chunk kernel ----------
     if (B < kRowBytes) {
@@ -347,7 +406,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             ctx->fail(DEMOD_E_INVAL, "buffer must hold whole chunks unless it ends the stream");
             return DEMOD_E_INVAL;
         }
-        return run_tiny(ctx, d_in, B, full, tail, d_out, stream);
+        return run_tiny(ctx, d_in, B, full, tail, d_out, stream, ctx->q1_table, q1_stride);
     }
 
     if (offset >= B || (offset & (kRowBytes - 1))) {
@@ -399,6 +458,13 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         fill_stencils(ctx, r);
         r.out_s16 = ctx->out_s16;
         r.out_scale = ctx->out_scale;
+        if (q1) {
+            r.q1_table = ctx->q1_table;
+            r.q1_stride = q1_stride;
+            const uint64_t tail = n_bytes % B;  // a short last chunk (of at least one row: smaller ones go to the literal kernel)
+            r.q1_last_chunk = tail ? (uint32_t) (n_bytes / B) : 0xFFFFFFFFu;
+            r.q1_last_k = (uint32_t) (tail / 2);
+        }
 
         ctx->last_row_launches = 0;
         const uint32_t ragged = (uint32_t) (row_bytes & (kRowBytes - 1));
@@ -408,7 +474,9 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         // that split runs in the fast build and may look ahead into the first
         // row after the split, which is a full row.
         uint32_t split = total_rows;
-        if (ragged) {
+        if (q1) {
+            split = 0;  // every row in the bounds-checked build, which reads the offsets table
+        } else if (ragged) {
             const uint32_t seg = 1u << seg_log2;
             const uint32_t phase = (uint32_t) (offset / kRowBytes);
             const uint32_t keep = total_rows >= 2 ? total_rows - 2 : 0;       // last full row index, at most
@@ -456,7 +524,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
                 p0 = p1;
             }
         }
-        if (ragged) {
+        if (ragged || (q1 && total_rows)) {
             RowLaunch a = r;
             a.in = d_in + (uint64_t) split * kRowBytes;
             a.out = d_out + (uint64_t) split * kRowOutputs * ob;
@@ -497,6 +565,10 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
         fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale, h.sec_pre, h.sos_pre);
         h.in_separate = pl.in_separate;
+        if (q1) {
+            h.q1_table = ctx->q1_table + 2ull * skip * q1_stride;  // (buffers start on a chunk boundary: head i is chunk i)
+            h.q1_stride = q1_stride;
+        }
         if (launch_heads(h, pl.conditioning, stream)) {
             ctx->fail(DEMOD_E_HIP, "demod_heads launch", hipGetLastError());
             return DEMOD_E_HIP;
@@ -504,7 +576,8 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     }
 
     if (tiny_tail) {
-        const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4 * ob, stream);
+        const int rc = run_tiny(ctx, d_in + row_bytes, kRowBytes, 0, tiny_tail, d_out + row_bytes / 4 * ob, stream,
+                                q1 ? ctx->q1_table + 2ull * (row_bytes / B) * q1_stride : nullptr, q1_stride);
         if (rc) return rc;
     }
     return DEMOD_OK;

@@ -42,6 +42,14 @@ struct demod_ctx {
     hipEvent_t tiny_done = nullptr;
     bool tiny_pending = false;
 
+    // -q1: the offsets table the correct_iq_offsets pass fills for one call (two floats per
+    // iteration), and the two offset pairs that carry the reference's static state from call
+    // to call (read from one, written to the other, swapped every call)
+    float *q1_table = nullptr;
+    uint64_t q1_pairs = 0;
+    float *q1_carry = nullptr;
+    int q1_flip = 0;
+
     HostPipe *pipe = nullptr;  // created by the first host-path call
     int rings = 0;             // streaming rings alive on this context (demod_ring_create)
 

@@ -32,6 +32,13 @@ struct RowLaunch {
     int32_t sec_in, sec_out;  // sections of the complex stage (0 = none) and of the output stage
     int32_t in_separate;      // Plan::in_separate
     float sos_in[4][6], sos_out[4][6];
+    // -q1 (kCorrectIq, bounds-checked build only): the running offsets of every iteration, one
+    // (re, im) pair per iteration, chunk c's at q1_table[c * q1_stride ..]; chunk 0 = the chunk
+    // that holds buffer row 0.  The stream's last chunk may be short: q1_last_chunk / q1_last_k.
+    const float *q1_table;
+    uint32_t q1_stride;      // entries (pairs) per chunk = chunk bytes / 4
+    uint32_t q1_last_chunk;  // index of the short last chunk, or 0xFFFFFFFF
+    uint32_t q1_last_k;      // its complex samples
     uint32_t ragged_bytes; // valid bytes of the last row (multiple of 4, < 1024), 0 = full
     float hin[kMaxTaps];
     float bias_im;
@@ -60,6 +67,8 @@ struct HeadLaunch {
     float sos_in[kMaxSections][6];
     float sos_out[kMaxSections][6];
     float scale;
+    const float *q1_table;     // -q1: offsets of head 0's chunk onwards (see RowLaunch), q1_stride pairs per chunk
+    uint32_t q1_stride;
 };
 
 // Whole-chunk literal kernel for chunks smaller than one row (B < 1024).
@@ -80,12 +89,29 @@ struct TinyLaunch {
     float sos_in[kMaxSections][6];
     float sos_out[kMaxSections][6];
     float scale;
+    const float *q1_table;     // -q1: offsets of chunk 0 onwards, q1_stride pairs per chunk
+    uint32_t q1_stride;
+};
+
+// -q1: replay of correctIq's offset recurrence (src/matrix.c:131-138), one thread per chunk.
+struct OffsetLaunch {
+    const uint8_t *in;         // first chunk
+    float *table;              // out: (re, im) offsets BEFORE every iteration, stride pairs per chunk
+    const float *carry_in;     // the two offsets the first chunk starts from
+    float *carry_out;          // ... and what the last chunk leaves
+    uint64_t chunk_bytes;
+    uint64_t n_chunks;         // full chunks
+    uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
+    uint32_t stride;           // table pairs per chunk = chunk_bytes / 4
+    uint32_t warm;             // iterations of run-in before a chunk (Plan::q1_warm)
+    float esr;
 };
 
 // Host-callable launchers (defined in kernels.hip).  `stream` is a hipStream_t.
 int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream);
 int launch_heads(const HeadLaunch &a, int conditioning, void *stream);
 int launch_tiny(const TinyLaunch &a, int conditioning, uint32_t threads, void *stream);
+int launch_offsets(const OffsetLaunch &a, void *stream);
 int launch_synth_fill(void *dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed, void *stream);
 // Device self-test helper: atan2 of n (y, x) pairs with the kernel's approximation.
 int launch_atan2_probe(const float *y, const float *x, float *out, uint32_t n, void *stream);

@@ -219,7 +219,13 @@ __device__ __forceinline__ float opaque_128() {
 template <int COND, bool FOLD = false>
 __device__ __forceinline__ void unpack_dword(uint32_t w, float scale, float &i0, float &q0, float &i1,
                                              float &q1) {
-    if constexpr (COND == kNormalize) {
+    if constexpr (COND == kCorrectIq) {
+        // the byte itself; its running offset is subtracted by the caller (src/matrix.c:131-135)
+        i0 = (float) (w & 0xFFu);
+        q0 = (float) ((w >> 8) & 0xFFu);
+        i1 = (float) ((w >> 16) & 0xFFu);
+        q1 = (float) (w >> 24);
+    } else if constexpr (COND == kNormalize) {
         // byte * (2/255) - 1, product and difference rounded separately (src/matrix.c:106,112)
         i0 = (float) (w & 0xFFu) * scale - 1.0f;
         q0 = (float) ((w >> 8) & 0xFFu) * scale - 1.0f;
@@ -250,8 +256,22 @@ __device__ __forceinline__ void unpack_dword(uint32_t w, float scale, float &i0,
 template <int COND>
 __device__ __forceinline__ float unpack_byte(uint8_t b, float scale) {
     if constexpr (COND == kNormalize) return (float) b * scale - 1.0f;
+    if constexpr (COND == kCorrectIq) return (float) b;  // minus its running offset, see q1_offset()
     return (float) (int8_t) (uint8_t) (b - 127);
 }
+
+// -q1: the offset pair complex sample k of a chunk of K samples was corrected with.  correctIq
+// walks a chunk from both ends at once: iteration t takes samples t and K-1-t with the same
+// offsets (src/matrix.c:131-135), so sample k belongs to iteration min(k, K-1-k).
+__device__ __forceinline__ float2 q1_offset(const float *chunk_table, int k, int K) {
+    const int t = k < K - 1 - k ? k : K - 1 - k;
+    return reinterpret_cast<const float2 *>(chunk_table)[t];
+}
+struct Q1Row {
+    const float *table;  // the chunk's offsets
+    int k0;              // chunk-local index of this lane's first complex sample
+    int K;               // complex samples of the chunk
+};
 
 // Look-ahead values a row needs from the row after it (lane 0 of that row).
 struct Halo {
@@ -362,7 +382,8 @@ constexpr bool fold_unpack() {
 // look-ahead values and takes this row's for the row before it; `lead`: see fast_atan2.
 template <int TIN, int TOUT, int COND, bool RAGGED, class EX>
 __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, EX &ex, int valid, float lead,
-                                            float (&y)[4]) {
+                                            float (&y)[4], const Q1Row q1 = Q1Row{nullptr, 0, 0}) {
+    static_assert(COND != kCorrectIq || RAGGED, "-q1 runs in the bounds-checked build");
     constexpr int NX = 8 + (TIN > 0 ? TIN - 1 : 0);
     constexpr int ND = 4 + TOUT - 1;
     float xr[NX], xi[NX];
@@ -371,6 +392,16 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
     unpack_dword<COND, FOLD>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
     unpack_dword<COND, FOLD>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
     unpack_dword<COND, FOLD>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+    if constexpr (COND == kCorrectIq) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (q1.k0 + k < q1.K) {
+                const float2 off = q1_offset(q1.table, q1.k0 + k, q1.K);
+                xr[k] = xr[k] - off.x;
+                xi[k] = xi[k] - off.y;
+            }
+        }
+    }
     if constexpr (RAGGED) {
         // past the end of a short final chunk the reference's buffers hold 0.0f
 #pragma unroll
@@ -705,14 +736,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD
             for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = 128.f;  // 0.0f in the folded domain
         }
         RegisterExchange ex{halo};
+        auto q1_row = [&](uint32_t r) -> Q1Row {
+            if constexpr (COND != kCorrectIq) return Q1Row{nullptr, 0, 0};
+            const uint32_t chunk = (g0 + r) >> a.rpc_log2;
+            const int K = chunk == a.q1_last_chunk ? (int) a.q1_last_k : (int) (512u << a.rpc_log2);
+            return Q1Row{a.q1_table + 2ull * chunk * a.q1_stride, (int) ((((g0 + r) & rpc_mask) << 9) + 8u * lane), K};
+        };
         if ((ge & rpc_mask) != 0 && re < a.rows_readable) {
             float unused[4];
-            process_row<TIN, TOUT, COND, true>(load(re), a, ex, lane_valid(re), kAtanLead, unused);
+            process_row<TIN, TOUT, COND, true>(load(re), a, ex, lane_valid(re), kAtanLead, unused, q1_row(re));
         }
         for (uint32_t r = re; r-- > rb;) {
             float y[4];
             const int valid = lane_valid(r);
-            process_row<TIN, TOUT, COND, true>(load(r), a, ex, valid, kAtanLead, y);
+            process_row<TIN, TOUT, COND, true>(load(r), a, ex, valid, kAtanLead, y, q1_row(r));
             const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
             char *dst = out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane);
             if (!head) {
@@ -909,13 +946,18 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
             raw[4 * v] = q.x; raw[4 * v + 1] = q.y; raw[4 * v + 2] = q.z; raw[4 * v + 3] = q.w;
         }
     }
+    auto q1 = [&](int k, int lane01, float v) -> float {  // -q1: minus the running offset of the sample's iteration
+        if constexpr (COND != kCorrectIq) return v;
+        const float2 off = q1_offset(a.q1_table + 2ull * c * a.q1_stride, k, K);
+        return v - (lane01 ? off.y : off.x);
+    };
     auto sample = [&](int k, int lane01) -> float {  // unpacked input, 0.0f past the chunk
         const int i = 2 * k + lane01;
         if constexpr (kFixed) {
             const uint8_t b = (uint8_t) (raw[i >> 2] >> (8 * (i & 3)));
-            return k < K ? unpack_byte<COND>(b, a.scale) : 0.f;
+            return k < K ? q1(k, lane01, unpack_byte<COND>(b, a.scale)) : 0.f;
         } else {
-            return k < K ? unpack_byte<COND>(bytes[i], a.scale) : 0.f;
+            return k < K ? q1(k, lane01, unpack_byte<COND>(bytes[i], a.scale)) : 0.f;
         }
     };
 
@@ -1078,7 +1120,14 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
         // and writes where the unpacked samples would otherwise be
         const bool pre = a.sec_pre > 0;  // -q2 in front of -L: highpassDc from its own buffer into F first
         float *X = (a.in_separate || pre) ? dem + a.chunk_bytes + kTinyPad : F;
-        for (uint32_t i = 0; i < B; ++i) X[i] = unpack_byte<COND>(bytes[i], a.scale);
+        for (uint32_t i = 0; i < B; ++i) {
+            float v = unpack_byte<COND>(bytes[i], a.scale);
+            if constexpr (COND == kCorrectIq) {
+                const float2 off = q1_offset(a.q1_table + 2ull * c * a.q1_stride, (int) (i >> 1), (int) (B >> 1));
+                v = v - ((i & 1u) ? off.y : off.x);
+            }
+            X[i] = v;
+        }
         float *src = F;
         float *y2 = F + B;
         if (pre) {
@@ -1128,6 +1177,60 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
             float *out = static_cast<float *>(a.out) + out0;
             for (uint32_t n = 0; n < Ld; ++n) out[n] = y2[n];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// -q1: the running offsets of correctIq (one thread per chunk)
+// ---------------------------------------------------------------------------
+// correctIq (src/matrix.c:120-140) walks a chunk from both ends: iteration t corrects complex
+// samples t and K-1-t with the offsets it finds and then moves them,
+//     off += ((byte[t] - off) + (byte[K-1-t] - off)) * esr        (re and im lanes alike),
+// and its static offsets carry on from chunk to chunk: a float recurrence over the whole stream,
+// every step rounded, so it cannot be re-associated.  It contracts, though -- a start value is
+// forgotten at the rate (1 - 2 esr) per iteration -- so each chunk's thread replays the literal
+// operations over the `warm` iterations BEFORE its chunk (from the call's carried-in state when
+// they reach that far back, from an arbitrary value otherwise: by then its influence has shrunk
+// below 2^-26 twice over and the float sequence has locked onto the reference's), then through
+// its own chunk, writing the offsets every iteration starts from.  -ffp-contract=off: the
+// reference's generic build rounds the sum, the product and the update separately.
+__global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
+    const uint64_t c = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
+    if (c >= total) return;
+    const uint64_t T = a.chunk_bytes >> 2;  // iterations of a full chunk
+    float off0, off1;
+    uint64_t cc = 0, t0 = 0;                // where the run-in starts: chunk, iteration
+    if (c * T <= (uint64_t) a.warm) {
+        off0 = a.carry_in[0];
+        off1 = a.carry_in[1];
+    } else {
+        const uint64_t g = c * T - a.warm;
+        cc = g / T;
+        t0 = g - cc * T;
+        off0 = off1 = 127.5f;
+    }
+    auto step = [&](const uint8_t *chunk, uint64_t len, uint64_t t) {
+        const uint8_t *f = chunk + 2 * t, *m = chunk + len - 2 * t - 2;
+        const float f0 = (float) f[0] - off0, m0 = (float) m[0] - off0;
+        const float f1 = (float) f[1] - off1, m1 = (float) m[1] - off1;
+        off0 += (f0 + m0) * a.esr;
+        off1 += (f1 + m1) * a.esr;
+    };
+    for (; cc < c; ++cc, t0 = 0) {
+        const uint8_t *chunk = a.in + cc * a.chunk_bytes;
+        for (uint64_t t = t0; t < T; ++t) step(chunk, a.chunk_bytes, t);
+    }
+    const uint64_t len = c < a.n_chunks ? a.chunk_bytes : a.tail_bytes;
+    const uint8_t *chunk = a.in + c * a.chunk_bytes;
+    float2 *row = reinterpret_cast<float2 *>(a.table) + c * a.stride;
+    for (uint64_t t = 0; t < (len >> 2); ++t) {
+        row[t] = make_float2(off0, off1);
+        step(chunk, len, t);
+    }
+    if (c == total - 1) {
+        a.carry_out[0] = off0;
+        a.carry_out[1] = off1;
     }
 }
 
@@ -1216,9 +1319,27 @@ int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
 
 uint32_t max_segment_rows() { return (uint32_t) kGroup; }
 
+namespace {
+// -q1: the bounds-checked build with the zero-padded 5-tap stencils, whatever the design
+template <int TIN>
+int launch_rows_q1(const RowLaunch &a, hipStream_t s) {
+    const uint32_t g0 = a.phase_rows, g1 = a.phase_rows + a.n_rows;
+    const uint32_t segs = ((g1 + (1u << a.seg_log2) - 1u) >> a.seg_log2) - (g0 >> a.seg_log2);
+    uint32_t blocks = (segs + (uint32_t) kWavesPerBlock - 1u) / (uint32_t) kWavesPerBlock;
+#if DEMOD_XCD_INTERLEAVE
+    blocks = (blocks + DEMOD_XCD_INTERLEAVE - 1u) / DEMOD_XCD_INTERLEAVE * DEMOD_XCD_INTERLEAVE;
+#endif
+    const dim3 threads(64 * kWavesPerBlock);
+    if (a.out_s16) hipLaunchKernelGGL((demod_rows<TIN, kMaxTaps, kCorrectIq, true, true>), dim3(blocks), threads, 0, s, a);
+    else hipLaunchKernelGGL((demod_rows<TIN, kMaxTaps, kCorrectIq, true, false>), dim3(blocks), threads, 0, s, a);
+    return hip_ok(hipGetLastError());
+}
+}  // namespace
+
 int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.n_rows == 0) return 0;
+    if (conditioning == kCorrectIq) return taps_in == 0 ? launch_rows_q1<0>(a, s) : launch_rows_q1<kMaxTaps>(a, s);
     if (conditioning == kNormalize) return launch_rows_c<kNormalize>(a, taps_in, taps_out, s);
     if (conditioning == kShiftOriginPlain) return launch_rows_c<kShiftOriginPlain>(a, taps_in, taps_out, s);
     return launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s);
@@ -1251,6 +1372,8 @@ int launch_heads(const HeadLaunch &a, int conditioning, void *stream) {
     if (a.n_heads == 0 || a.head_outputs == 0) return 0;
     if (conditioning == kNormalize)
         launch_heads_c<kNormalize>(a, s);
+    else if (conditioning == kCorrectIq)
+        launch_heads_c<kCorrectIq>(a, s);
     else
         launch_heads_c<kShiftOrigin>(a, s);
     return hip_ok(hipGetLastError());
@@ -1262,8 +1385,18 @@ int launch_tiny(const TinyLaunch &a, int conditioning, uint32_t threads, void *s
     if (blocks == 0) return 0;
     if (conditioning == kNormalize)
         hipLaunchKernelGGL(demod_tiny<kNormalize>, dim3(blocks), dim3(64), 0, s, a);
+    else if (conditioning == kCorrectIq)
+        hipLaunchKernelGGL(demod_tiny<kCorrectIq>, dim3(blocks), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(demod_tiny<kShiftOrigin>, dim3(blocks), dim3(64), 0, s, a);
+    return hip_ok(hipGetLastError());
+}
+
+int launch_offsets(const OffsetLaunch &a, void *stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(correct_iq_offsets, dim3((uint32_t) ((total + 63) / 64)), dim3(64), 0, s, a);
     return hip_ok(hipGetLastError());
 }
 

@@ -11,7 +11,7 @@
  *   -L cutoff   input lowpass (default none)     -d/-D n     output / input filter degree
  *   -m bits     1: output filter Chebyshev-I, 2: input filter Chebyshev-I
  *   -e x        Chebyshev ripple parameter x/10  -b n        chunk = 262144 << n (n < 0 shifts right)
- *   -q 0|2|3    IQ conditioning (0 shiftOrigin, 2 highpassDc, 3 normalizeInput)   -c n   demod mode bits
+ *   -q 0|1|2|3  IQ conditioning (0 shiftOrigin, 1 correctIq, 2 highpassDc, 3 normalizeInput)   -c n   demod mode bits
  *   -r, -n      accepted and ignored, as in the reference
  *
  * Structure: the main thread is the producer (fread into the pinned hand-off
@@ -35,7 +35,7 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s -i <in|-> -o <out|-> [-S rate] [-l cutoff] [-L cutoff] [-d deg] [-D deg]\n"
-            "          [-m mode] [-e ripple] [-b shift] [-q 0|2|3] [-c bits]\n",
+            "          [-m mode] [-e ripple] [-b shift] [-q 0|1|2|3] [-c bits]\n",
             argv0);
 }
 

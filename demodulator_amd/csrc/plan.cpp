@@ -187,7 +187,7 @@ double stage_bound(const Stage &st, double in, double init) {
 // plan neither the reference nor this path ever leaves the finite floats and the rule is
 // vacuous.  Designs beyond the limit are refused (the reference prints inf / NaN->0 garbage).
 double plan_magnitude_bound(const Plan &pl) {
-    const double x = pl.conditioning == kNormalize ? 1.0 : 128.0;
+    const double x = pl.conditioning == kNormalize ? 1.0 : pl.conditioning == kCorrectIq ? 256.0 : 128.0;
     double z = x;
     if (pl.pre.sections) z = stage_bound(pl.pre, z, 0.0);
     double worst = z;
@@ -211,11 +211,6 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
 
     if (demod_mode == 0) {
         err = "demod mode 0 (raw filtered IQ output, src/matrix.c:244-251) is not part of this path";
-        return false;
-    }
-    if (iq_mode == 1) {
-        err = "-q1 (correctIq, src/matrix.c:120-140) carries state from chunk to chunk and is not part of "
-              "this path";
         return false;
     }
     const bool cascade = iq_mode == 2 && o.lowpass_in != 0;
@@ -242,7 +237,19 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
 
     plan = Plan{};
     plan.chunk_bytes = o.buf_size;
-    plan.conditioning = iq_mode == 3 ? kNormalize : iq_mode == 2 ? kShiftOriginPlain : kShiftOrigin;
+    plan.conditioning = iq_mode == 3 ? kNormalize : iq_mode == 2 ? kShiftOriginPlain : iq_mode == 1 ? kCorrectIq : kShiftOrigin;
+    if (iq_mode == 1) {
+        plan.esr = (float) (50. / o.sample_rate);  // src/matrix.c:210
+        // the offsets' recurrence off' = off (1 - 2 esr) + (byte + mirror byte) esr forgets its start:
+        // iterations until a difference of 255 has shrunk below 2^-26, twice over
+        const double decay = 2.0 * (double) plan.esr;
+        if (!(decay > 1e-9) || !(decay < 1.0)) {
+            err = "-q1: the sample rate puts the offset recurrence (src/matrix.c:137-138) outside 0 < 100/S < 1";
+            return false;
+        }
+        const double need = std::log(255.0 * 67108864.0) / -std::log1p(-decay);
+        plan.q1_warm = (uint32_t) std::min(2.0 * need + 64.0, 4.0e9);
+    }
     plan.prefilter = in_degree != 0 || iq_mode == 2;
     plan.in_separate = iq_mode == 2 && !cascade;
 

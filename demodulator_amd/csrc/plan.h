@@ -33,7 +33,10 @@ Options options_from_params(const demod_params &p);
 // stencil's constant (kernels.hip, fold_unpack): the -q2 highpass taps (+3, -1) cancel for
 // samples with x[k+1] = 3 x[k], and there the result has to be as precise as the samples are
 // small, not as 128 + sample is.
-enum Conditioning : int { kShiftOrigin = 0, kShiftOriginPlain = 1, kNormalize = 3 };
+// kCorrectIq (-q1): byte minus a running DC offset that the reference carries from sample pair to
+// sample pair and from chunk to chunk (src/matrix.c:120-140); the offsets are replayed by a
+// pass of their own into a table the other kernels read (kernels.hip, correct_iq_offsets).
+enum Conditioning : int { kShiftOrigin = 0, kShiftOriginPlain = 1, kNormalize = 3, kCorrectIq = 4 };
 
 struct Stage {
     int sections = 0;                 // S = ceil(degree / 2)
@@ -63,6 +66,11 @@ struct Plan {
     int head_outputs = 0;  // H: outputs per chunk that the closed form does not cover
     int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row that leave their store to the head kernel
     double magnitude_bound = 0;  // plan_magnitude_bound(): every float of the path stays below this
+    // -q1: offsets move by (sum of the two corrected samples of an iteration) * esr, esr = (float)(50 / S)
+    // (src/matrix.c:137-138,210); after q1_warm iterations a start value has decayed below half an
+    // ulp of the offsets many times over ((1 - 2 esr)^n * 255 < 2^-26 at n = q1_warm / 2)
+    float esr = 0.f;
+    uint32_t q1_warm = 0;
 };
 
 // Bound on the magnitude of every intermediate and result of the path for a plan (finite

@@ -61,7 +61,8 @@ typedef struct demod_params {
     uint32_t mode;        /* ww|dd|qq|ff byte, default 0x10 (src/main.c:112):
                              bit0 output filter Chebyshev-I, bit1 input filter
                              Chebyshev-I, bits2-3 IQ conditioning (-q: 0
-                             shiftOrigin, 3 normalizeInput), bits4-5 demod mode */
+                             shiftOrigin, 1 correctIq, 2 highpassDc, 3
+                             normalizeInput), bits4-5 demod mode */
     uint32_t reserved;
     uint64_t buf_size;    /* chunk bytes B (DEFAULT_BUF_SIZE shifted by -b); power of two >= 4 */
 } demod_params;
@@ -96,8 +97,12 @@ int demod_abi_version(void);
 /* Create a context on HIP device `device`: designs the filters on the host,
  * derives the stencil taps and uploads nothing until the first process call.
  * Fails with DEMOD_E_INVAL for option sets the reference leaves undefined
- * (-D without -L, src/matrix.c:227-231) or that are out of scope (-q1, demod
- * mode 0), with a message in demod_last_error(NULL). */
+ * (-D without -L, src/matrix.c:227-231) or that are out of scope (demod mode 0),
+ * with a message in demod_last_error(NULL).
+ * -q1 (correctIq, src/matrix.c:120-140) keeps running offsets through the whole
+ * stream, as the reference's static state does: the context carries them from call
+ * to call, so its buffers must be whole chunks from a chunk boundary (a short last
+ * chunk ends the stream), handed over in stream order on one HIP stream. */
 int demod_create(const demod_params *p, int device, demod_ctx **out);
 void demod_destroy(demod_ctx *ctx);
 

@@ -10,8 +10,9 @@ Domain: full chunks (the tail follows the build's deterministic policy, Appendix
     +-pi results must match exactly, which this bound enforces (a wrong sign is an error of
     2*pi*|h|).
 
-(2) INEXACT path -- with -L, with -q2 (highpassDc, a complex stage like -L's) or with -q3
-    (normalizeInput: samples byte*2/255-1 are rounded values):
+(2) INEXACT path -- with -L, with -q2 (highpassDc, a complex stage like -L's), with -q3
+    (normalizeInput: samples byte*2/255-1 are rounded values) or with -q1 (correctIq: byte minus
+    a running offset):
         |gpu - ref| <= 2e-5 * g * max(1, |ref|) + cond(n)   for >= 99.999 % of the outputs,
         |gpu - ref| <= 1e-4 * g * max(1, |ref|) + cond(n)   for the rest,
     except WRAP OUTLIERS: the difference is a combination of +-2*pi*h_out[j] (to within the
@@ -105,9 +106,9 @@ class Report:
 
 
 def inexact_path(lowpass_in: float, mode: int) -> bool:
-    """True when the discriminator arguments are rounded values (-L, -q2, -q3):
+    """True when the discriminator arguments are rounded values (-L, -q1, -q2, -q3):
     selects criterion (2)."""
-    return lowpass_in != 0 or ((mode >> 2) & 3) in (2, 3)
+    return lowpass_in != 0 or ((mode >> 2) & 3) in (1, 2, 3)
 
 
 def abs_taps(sos: np.ndarray) -> tuple[np.ndarray, float]:
@@ -147,7 +148,10 @@ def conditioning(dm, opt, data: np.ndarray) -> Conditioning | None:
     g = np.abs(np.asarray(dout["taps"], dtype=np.float64))
     data = np.asarray(data, dtype=np.uint8)
     n = data.size & ~3
-    if iq == 3:
+    if iq == 1:
+        x = correct_iq_model(data[:n], opt.buf_size, float(np.float32(50.0 / opt.sample_rate)))
+        xerr = 2.0 ** -24 * 512                                     # byte - offset is rounded, and so is every offset
+    elif iq == 3:
         x = data[:n].astype(np.float64) * (2.0 / 255.0) - 1.0     # normalizeInput
         xerr = 2.0 ** -24                                           # the samples themselves are rounded
     else:
@@ -196,6 +200,35 @@ def conditioning(dm, opt, data: np.ndarray) -> Conditioning | None:
         out_cond[pos // 4:pos // 4 + min(H, m)] = 0.0
         pos += ln
     return Conditioning(out_cond, out_axis, int(dout["head_outputs"]))
+
+
+def correct_iq_model(data: np.ndarray, chunk_bytes: int, esr: float) -> np.ndarray:
+    """-q1 in float64: byte minus the running offset of its iteration (src/matrix.c:120-140).
+    Iteration t of a chunk takes complex samples t and K-1-t with the offsets it finds, then
+    off += ((front - off) + (back - off)) * esr, i.e. off' = (1 - 2 esr) off + esr (front + back);
+    the offsets carry on from chunk to chunk."""
+    from scipy.signal import lfilter
+    b = np.asarray(data, dtype=np.float64)
+    n = b.size
+    x = np.empty(n)
+    a = 1.0 - 2.0 * esr
+    carry = np.zeros(2)
+    pos = 0
+    while pos < n:
+        ln = min(chunk_bytes, n - pos)
+        c = b[pos:pos + ln]
+        T, K = ln // 4, ln // 2
+        for lane in (0, 1):
+            u = c[lane:2 * T:2] + c[ln - 2 + lane - 2 * np.arange(T)]          # front + mirrored back byte per iteration
+            y, _ = lfilter([esr], [1.0, -a], u, zi=[a * carry[lane]])
+            before = np.concatenate([[carry[lane]], y[:-1]]) if T else np.zeros(0)
+            k = np.arange(K)
+            t = np.minimum(k, K - 1 - k)
+            x[pos + lane:pos + ln:2] = c[lane::2] - before[t]
+            if T:
+                carry[lane] = y[-1]
+        pos += ln
+    return x
 
 
 def gain_of(taps_out) -> float:
@@ -256,6 +289,8 @@ def compare_stream(dm, opt, got, want, data, *, use_cond: bool = True) -> Report
     inexact = inexact_path(opt.lowpass_in, opt.mode)
     if not inexact or data is None or not use_cond:
         return compare(got, want, taps, inexact, None)
+    if ((opt.mode >> 2) & 3) == 1:      # -q1: a chunk's samples depend on every chunk before it: the model needs the stream
+        return compare(got, want, taps, True, conditioning(dm, opt, data))
     got = np.asarray(got)
     want = np.asarray(want)
     n = want.size

@@ -186,3 +186,16 @@ def test_cli_large_file_to_file_in_batches(tmp_path):
     # ... and through a pipe (fwrite) the same
     out = _run([DEMOD, "-i", str(src), "-o", "-", "-L", "12500", "-l", "6500"], b"")
     assert np.array_equal(np.frombuffer(out, dtype=np.uint32), want.view(np.uint32))
+
+
+def test_cli_correct_iq_q1(manifest, golden):
+    """-q 1 (correctIq) through the CLI against the golden vector of the compiled reference: every
+    hand-off is a call of its own, the running offsets carry over on the device."""
+    for name, extra in (("q1_b32768", ["-b", "-3"]), ("q1_L_b16384", ["-b", "-4", "-L", "12500", "-l", "6500"]), ("q1_b1024", ["-b", "-8"])):
+        c = manifest["streams"][name]
+        opt = dm.Options(**c["flags"])
+        data = oracle.synth_bytes(c["seed"], 0, c["n_chunks"] * opt.buf_size)
+        out = _run([DEMOD, "-i", "-", "-o", "-", "-q", "1"] + extra, data.tobytes())
+        got = np.frombuffer(out, dtype=np.float32)
+        assert got.size == data.size // 4
+        check(dm, opt, got, golden(c["file"]), data, name=name)

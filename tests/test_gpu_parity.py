@@ -399,6 +399,8 @@ def test_random_option_sets_and_lengths(orc):
         mode = 0x10 | int(rng.choice([0, 0, 1, 2, 3])) | (0xC if rng.random() < 0.2 else 0)
         if rng.random() < 0.2:
             mode = (mode & ~0xC) | 0x8      # -q2 highpassDc, alone or in front of -L
+        elif rng.random() < 0.15:
+            mode = (mode & ~0xC) | 0x4      # -q1 correctIq: running offsets carried from chunk to chunk
         opt = dm.Options(sample_rate=float(rng.choice([96000.0, 125000.0, 192000.0])),
                          lowpass_in=float(rng.choice([9600.0, 12500.0])) if with_in else 0.0,
                          lowpass_out=float(rng.choice([6500.0, 12500.0])),
@@ -629,3 +631,57 @@ def test_tiny_chunks_through_the_pipelined_host_paths(orc, flags, B):
         if B == 64:
             big = oracle.synth_bytes(0x7272, 0, (40 << 20) + 64 * 3)     # two staging pieces
             _check("process_host 40 MiB B=64", d.process_host(big), orc.process(fl, big, threads=_oracle_threads()), opt, big)
+
+
+# -- -q1 correctIq: running offsets, carried from chunk to chunk and from call to call ----------
+
+@pytest.mark.parametrize("kw,n_bytes", [
+    (dict(buf_size=262144), 5 * 262144 + 70000),                                       # default chunk, short last chunk of 68 rows
+    (dict(buf_size=16384, lowpass_in=12500.0, lowpass_out=6500.0), 40 * 16384 + 500),  # both filters, sub-row tail
+    (dict(buf_size=1024, sample_rate=96000.0, out_degree=5), 300 * 1024 + 1024),       # one-row chunks: the carried state decides
+    (dict(buf_size=64), 5000 * 64 + 20),                                               # chunks below one row (literal kernel)
+    (dict(buf_size=4096, lowpass_in=9600.0, in_degree=6, out_degree=7, sample_rate=192000.0), 64 * 4096),  # 3-tap designs, slow decay
+], ids=["default", "L_16k", "1k_S96k_d5", "b64", "D6d7_S192k"])
+def test_correct_iq_q1(orc, kw, n_bytes):
+    """-q1 (src/matrix.c:120-140): the offsets are a float recurrence over the whole stream.  Its
+    literal operations are replayed per chunk after a run-in (correct_iq_offsets), so the path
+    follows the reference's generic build operation for operation: parity with the oracle under
+    the one criterion; one call == the same stream in several calls (the state carries over on
+    the device) == the pinned ring, bit for bit."""
+    import torch
+    opt = dm.Options(mode=0x14, **kw)
+    B = opt.buf_size
+    data = oracle.synth_bytes(0x91 + B, 0, n_bytes)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    with dm.Demodulator(opt) as d:
+        whole = d.process_host(data)
+        _check(f"q1 {kw}", whole, want, opt, data)
+    iq = torch.from_numpy(data[: n_bytes & ~3].copy()).cuda()
+    n_chunks = n_bytes // B
+    cuts = sorted({0, (n_chunks // 3) * B, (n_chunks // 3 + 1) * B, (2 * n_chunks // 3) * B, n_bytes & ~3})
+    with dm.Demodulator(opt) as d:                      # a fresh context: the offsets start at zero again
+        parts = [d.process(iq[a:b].clone(), end_of_stream=(b == (n_bytes & ~3))) for a, b in zip(cuts[:-1], cuts[1:])]
+        torch.cuda.synchronize()
+        got = torch.cat(parts).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+        with pytest.raises(dm.DemodError, match="chunk to chunk"):
+            d.process(iq[:4096].clone(), chunk_offset=1024) if B > 1024 else d.process(iq[: B + 4].clone(), end_of_stream=False)
+    if B >= 1024:
+        import threading
+        with dm.Demodulator(opt) as d, d.ring() as ring:
+            parts = []
+
+            def consume():
+                while (p := ring.take()) is not None:
+                    parts.append(p)
+
+            t = threading.Thread(target=consume)
+            t.start()
+            for pos in range(0, n_bytes & ~3, B):
+                chunk = data[pos:pos + B]
+                ring.put(chunk, final=chunk.size < B)
+            if (n_bytes & ~3) % B == 0:
+                ring.put(np.zeros(0, np.uint8), final=True)
+            t.join(timeout=120)
+            assert not t.is_alive()
+            assert np.array_equal(np.concatenate(parts).view(np.uint32), whole.view(np.uint32))

@@ -101,7 +101,7 @@ def test_taps_reproduce_the_recurrence_in_the_interior():
 def test_rejected_option_sets():
     bad = [
         dm.Options(in_degree=3),                         # -D without -L (src/matrix.c:227-231)
-        dm.Options(mode=0x14),                           # -q1 correctIq
+        dm.Options(mode=0x14, sample_rate=90.0),         # -q1 with 100/S >= 1: the offset recurrence does not contract
         dm.Options(mode=0x18, lowpass_in=12500.0, in_degree=14),  # -q2 + -L with a long input stencil
         dm.Options(mode=0x00),                           # demod mode 0
         dm.Options(out_degree=0),
