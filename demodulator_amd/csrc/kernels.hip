@@ -1210,24 +1210,54 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         t0 = g - cc * T;
         off0 = off1 = 127.5f;
     }
-    auto step = [&](const uint8_t *chunk, uint64_t len, uint64_t t) {
-        const uint8_t *f = chunk + 2 * t, *m = chunk + len - 2 * t - 2;
-        const float f0 = (float) f[0] - off0, m0 = (float) m[0] - off0;
-        const float f1 = (float) f[1] - off1, m1 = (float) m[1] - off1;
+    auto update = [&](uint32_t fb0, uint32_t fb1, uint32_t mb0, uint32_t mb1) {
+        const float f0 = (float) fb0 - off0, m0 = (float) mb0 - off0;
+        const float f1 = (float) fb1 - off1, m1 = (float) mb1 - off1;
         off0 += (f0 + m0) * a.esr;
         off1 += (f1 + m1) * a.esr;
     };
-    for (; cc < c; ++cc, t0 = 0) {
-        const uint8_t *chunk = a.in + cc * a.chunk_bytes;
-        for (uint64_t t = t0; t < T; ++t) step(chunk, a.chunk_bytes, t);
-    }
+    auto byte_of = [](const uint4 &v, int i) -> uint32_t {
+        const uint32_t w = i < 4 ? v.x : i < 8 ? v.y : i < 12 ? v.z : v.w;
+        return (w >> (8 * (i & 3))) & 0xFFu;
+    };
+    // iterations [t0, t1) of a chunk of `len` bytes; `row` (or null) receives the offsets every
+    // iteration starts from.  Eight iterations per pair of 16-byte loads where alignment allows
+    // (the thread is alone with a long dependent chain: the loads must not be on it), the next
+    // pair requested before the current one is worked through.
+    auto run = [&](const uint8_t *chunk, uint64_t len, uint64_t t0, uint64_t t1, float2 *row) {
+        uint64_t t = t0;
+        auto single = [&]() {
+            const uint8_t *f = chunk + 2 * t, *m = chunk + len - 2 * t - 2;
+            if (row) row[t] = make_float2(off0, off1);
+            update(f[0], f[1], m[0], m[1]);
+            ++t;
+        };
+        const bool wide = (len & 15u) == 0 && (((uintptr_t) chunk) & 15u) == 0;
+        if (wide) {
+            while (t < t1 && (t & 7u)) single();
+            if (t + 8 <= t1) {
+                uint4 f = *reinterpret_cast<const uint4 *>(chunk + 2 * t);
+                uint4 m = *reinterpret_cast<const uint4 *>(chunk + len - 2 * t - 16);
+                for (; t + 8 <= t1; t += 8) {
+                    const bool more = t + 16 <= t1;
+                    const uint64_t tn = more ? t + 8 : t;
+                    const uint4 fn = *reinterpret_cast<const uint4 *>(chunk + 2 * tn);
+                    const uint4 mn = *reinterpret_cast<const uint4 *>(chunk + len - 2 * tn - 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (row) row[t + j] = make_float2(off0, off1);
+                        update(byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
+                    }
+                    f = fn;
+                    m = mn;
+                }
+            }
+        }
+        while (t < t1) single();
+    };
+    for (; cc < c; ++cc, t0 = 0) run(a.in + cc * a.chunk_bytes, a.chunk_bytes, t0, T, nullptr);
     const uint64_t len = c < a.n_chunks ? a.chunk_bytes : a.tail_bytes;
-    const uint8_t *chunk = a.in + c * a.chunk_bytes;
-    float2 *row = reinterpret_cast<float2 *>(a.table) + c * a.stride;
-    for (uint64_t t = 0; t < (len >> 2); ++t) {
-        row[t] = make_float2(off0, off1);
-        step(chunk, len, t);
-    }
+    run(a.in + c * a.chunk_bytes, len, 0, len >> 2, reinterpret_cast<float2 *>(a.table) + c * a.stride);
     if (c == total - 1) {
         a.carry_out[0] = off0;
         a.carry_out[1] = off1;
