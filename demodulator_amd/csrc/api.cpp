@@ -438,7 +438,8 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
 
     const uint32_t rpc_log2 = log2u(B / kRowBytes);
     uint32_t seg_log2 = log2u(ctx->seg_rows ? std::min(ctx->seg_rows, max_segment_rows()) : max_segment_rows());
-    seg_log2 = std::min(seg_log2, rpc_log2);
+    // (a segment spans several chunks when chunks are shorter than it: the kernels restart the
+    // look-ahead at every chunk boundary inside a segment)
 
     // chunk heads that start inside the buffer
     const uint64_t first_head = offset == 0 ? 0 : B - offset;

@@ -25,7 +25,7 @@ struct RowLaunch {
     uint32_t rows_readable; // rows that exist at `in` (>= n_rows): a launch may look ahead into the row after its last
     uint32_t phase_rows;   // chunk-local row index of buffer row 0
     uint32_t rpc_log2;     // log2(rows per chunk)
-    uint32_t seg_log2;     // log2(rows per wavefront segment), <= rpc_log2
+    uint32_t seg_log2;     // log2(rows per wavefront segment); a segment may span chunks shorter than it
     uint32_t head_quads;   // lanes of a chunk's row 0 whose outputs are chunk-head outputs (ceil(H / 4))
     // chunk head replayed by the wavefront that owns the chunk's row 0 (kernels.hip chunk_head); 0: left to demod_heads
     uint32_t fused_heads;

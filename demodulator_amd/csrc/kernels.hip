@@ -288,16 +288,23 @@ struct Halo {
 // (1) Registers: v_mov_b32 with a DPP wave shift inside the row, the following
 //     row's lane-0 values in scalar registers (v_readfirstlane).  Three VALU
 //     operations per value and row; used by the bounds-checked build.
+//
+// `edge`: this row starts a chunk.  What its lane 0 hands to the row before it is then not its
+// own values but what the reference finds past a chunk's end: 0.0f samples (`past` = 128 where
+// the unpack bias is folded), 0.0f discriminator outputs.  (A segment spans chunks when chunks
+// are shorter than a segment.)
 struct RegisterExchange {
     Halo &halo;
+    bool edge = false;
+    float past = 0.f;
     template <int N>
     __device__ __forceinline__ void next_x(float *xr, float *xi) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             xr[8 + j] = from_next_lane(xr[j], halo.xr[j]);
             xi[8 + j] = from_next_lane(xi[j], halo.xi[j]);
-            halo.xr[j] = wave_first(xr[j]);
-            halo.xi[j] = wave_first(xi[j]);
+            halo.xr[j] = edge ? past : wave_first(xr[j]);
+            halo.xi[j] = edge ? past : wave_first(xi[j]);
         }
     }
     template <int N>
@@ -305,7 +312,7 @@ struct RegisterExchange {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             d[4 + j] = from_next_lane(d[j], halo.d[j]);
-            halo.d[j] = wave_first(d[j]);
+            halo.d[j] = edge ? 0.f : wave_first(d[j]);
         }
     }
 };
@@ -323,13 +330,15 @@ struct LdsExchange {
     const lds_float *rd_x;
     lds_float *wr_d;
     const lds_float *rd_d;
+    bool edge0 = false;  // lane 0 of a row that starts a chunk: publishes past-the-end values (see RegisterExchange)
+    float past = 0.f;
     template <int N>
     __device__ __forceinline__ void next_x(float *xr, float *xi) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             f32x2 v;
-            v.x = xr[j];
-            v.y = xi[j];
+            v.x = edge0 ? past : xr[j];
+            v.y = edge0 ? past : xi[j];
             *reinterpret_cast<__attribute__((address_space(3))) f32x2 *>(wr_x + 2 * j) = v;
         }
         __builtin_amdgcn_wave_barrier();
@@ -343,7 +352,7 @@ struct LdsExchange {
     template <int N>
     __device__ __forceinline__ void next_d(float *d) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) wr_d[j] = d[j];
+        for (int j = 0; j < N; ++j) wr_d[j] = edge0 ? 0.f : d[j];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < N; ++j) d[4 + j] = rd_d[j];
@@ -683,9 +692,13 @@ __device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *ch
 #ifndef DEMOD_MIN_WAVES_PER_SIMD
 #define DEMOD_MIN_WAVES_PER_SIMD 8
 #endif
-template <int TIN, int TOUT, int COND, bool RAGGED, bool S16>
-// (the int16 store needs a few registers more: 7 wavefronts per SIMD rather than spills)
-__global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD - 1 : DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
+// SPAN: chunks are shorter than a segment (1-2 KiB chunks), so a segment holds several chunks and
+// the look-ahead restarts inside it (LdsExchange::edge0); a build of its own, because the extra
+// selects do not fit the 64-register budget of the streaming build, and a spilled register of a
+// load in flight would be read before it has landed (tools/check_asm_waits.py finds those).
+// (The int16 store and SPAN need a few registers more: 7 wavefronts per SIMD rather than spills.)
+template <int TIN, int TOUT, int COND, bool RAGGED, bool S16, bool SPAN = false>
+__global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVES_PER_SIMD - 1 : DEMOD_MIN_WAVES_PER_SIMD) void demod_rows(const RowLaunch a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if DEMOD_XCD_INTERLEAVE
@@ -735,7 +748,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD
 #pragma unroll
             for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = 128.f;  // 0.0f in the folded domain
         }
-        RegisterExchange ex{halo};
+        RegisterExchange ex{halo, false, fold_unpack<TIN, COND, true>() ? 128.f : 0.f};
         auto q1_row = [&](uint32_t r) -> Q1Row {
             if constexpr (COND != kCorrectIq) return Q1Row{nullptr, 0, 0};
             const uint32_t chunk = (g0 + r) >> a.rpc_log2;
@@ -749,6 +762,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD
         for (uint32_t r = re; r-- > rb;) {
             float y[4];
             const int valid = lane_valid(r);
+            ex.edge = ((g0 + r) & rpc_mask) == 0u;
             process_row<TIN, TOUT, COND, true>(load(r), a, ex, valid, kAtanLead, y, q1_row(r));
             const bool head = (((g0 + r) & rpc_mask) == 0u) && lane < a.head_quads;
             char *dst = out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane);
@@ -880,7 +894,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD
                 const uint32_t r = re - 1u - (uint32_t) k;
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
                 float y[4];
-                LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1]};
+                LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1],
+                               SPAN && lane == 0u && ((g0 + r) & rpc_mask) == 0u, kPastEnd};
                 process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
                 // (the first lanes of a chunk's first row hold interior-formula values for
                 // outputs that are not interior: chunk_head / demod_heads overwrites them)
@@ -895,9 +910,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, S16 ? DEMOD_MIN_WAVES_PER_SIMD
         };
         if (re - rb == (uint32_t) kGroup) segment(std::true_type{});
         else segment(std::false_type{});
-        // ---- the chunk's head, if this segment starts a chunk -----------------
-        if (a.fused_heads != 0u && (gs & rpc_mask) == 0u && gs >= g0)
-            chunk_head<COND, S16>(a, a.in + (uint64_t) rb * kRowBytes, (uint64_t) rb * kRowOutputs, lane);
+        // ---- the heads of the chunks that start in this segment ---------------
+        // (one, in the segment's first row, unless chunks are shorter than a segment)
+        if constexpr (SPAN) {
+            if (a.fused_heads != 0u) {
+                for (uint32_t r = rb; r < re; ++r)
+                    if (((g0 + r) & rpc_mask) == 0u)
+                        chunk_head<COND, S16>(a, a.in + (uint64_t) r * kRowBytes, (uint64_t) r * kRowOutputs, lane);
+            }
+        } else {
+            if (a.fused_heads != 0u && (gs & rpc_mask) == 0u && gs >= g0)
+                chunk_head<COND, S16>(a, a.in + (uint64_t) rb * kRowBytes, (uint64_t) rb * kRowOutputs, lane);
+        }
     }
 }
 
@@ -1306,14 +1330,19 @@ int launch_rows_t(const RowLaunch &a, hipStream_t s) {
     blocks = (blocks + DEMOD_XCD_INTERLEAVE - 1u) / DEMOD_XCD_INTERLEAVE * DEMOD_XCD_INTERLEAVE;
 #endif
     const dim3 threads(64 * kWavesPerBlock);
+    const bool span = a.rpc_log2 < a.seg_log2;  // chunks shorter than a segment
     if (a.out_s16) {
         if (a.ragged_bytes)
             hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, true, true>), dim3(blocks), threads, 0, s, a);
+        else if (span)
+            hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false, true, true>), dim3(blocks), threads, 0, s, a);
         else
             hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false, true>), dim3(blocks), threads, 0, s, a);
     } else {
         if (a.ragged_bytes)
             hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, true, false>), dim3(blocks), threads, 0, s, a);
+        else if (span)
+            hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false, false, true>), dim3(blocks), threads, 0, s, a);
         else
             hipLaunchKernelGGL((demod_rows<TIN, TOUT, COND, false, false>), dim3(blocks), threads, 0, s, a);
     }
