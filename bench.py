@@ -4,7 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c2|c3|c4|c5]
 
 A "step" is one pass of the hot path (one call of demod_process_device through
-the C ABI: the fused streaming kernel + the chunk-head kernel) over one shard of
+the C ABI: the fused streaming kernel, chunk heads included) over one shard of
 synthetic uint8 IQ that is already resident in HBM.  Metric: IQ Msamples/s of
 input (1 sample = 2 bytes in, 0.5 float32 out), whole job.
 

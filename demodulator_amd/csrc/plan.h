@@ -64,7 +64,7 @@ struct Plan {
     Stage stencil_in;
     Stage out;   // real output filter (-l)
     int head_outputs = 0;  // H: outputs per chunk that the closed form does not cover
-    int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row that leave their store to the head kernel
+    int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row whose outputs are chunk-head outputs (replayed literally)
     double magnitude_bound = 0;  // plan_magnitude_bound(): every float of the path stays below this
     // -q1: offsets move by (sum of the two corrected samples of an iteration) * esr, esr = (float)(50 / S)
     // (src/matrix.c:137-138,210); after q1_warm iterations a start value has decayed below half an

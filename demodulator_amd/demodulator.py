@@ -77,7 +77,7 @@ class Demodulator:
     """One demodulation context on one GPU.
 
     process()       device tensor in -> device tensor out (the hot path)
-    process_host()  numpy in -> numpy out through the pinned double-buffered path
+    process_host()  numpy in -> numpy out through the three-stream host pipeline
     """
 
     def __init__(self, options: Options | None = None, device: int = 0, **kw):

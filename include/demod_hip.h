@@ -239,7 +239,7 @@ int demod_synchronize(demod_ctx *ctx);
 
 /* Introspection (tests): the designed second-order sections
  * {b0,b1,b2,a0,a1,a2} as float rows, the stencil taps derived from them and
- * the per-chunk head length handled by the chunk-head kernel.
+ * the per-chunk head length that is replayed literally (chunk_head / demod_heads).
  * which: 0 = output filter, 1 = input filter (-L, or the -q2 highpass when alone), 2 = the -q2
  * highpass when it runs in front of -L.  Taps of the input filter are those of the stencil
  * the streaming kernel applies: with -q2 and -L both on, the composition of the two.
