@@ -299,6 +299,8 @@ static int run_offsets(demod_ctx *ctx, const uint8_t *d_in, uint64_t n_bytes, ui
     o.tail_bytes = (uint32_t) (n_bytes - o.n_chunks * B);
     o.stride = (uint32_t) (B / 4);
     o.warm = pl.q1_warm;
+    // pieces of at least 4096 iterations: beyond that the run-in, which every piece repeats, is the chain
+    o.parts = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(16, (B / 4) / 4096));
     o.esr = pl.esr;
     if (launch_offsets(o, stream)) {
         ctx->fail(DEMOD_E_HIP, "correct_iq_offsets launch", hipGetLastError());

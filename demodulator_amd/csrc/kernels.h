@@ -104,6 +104,7 @@ struct OffsetLaunch {
     uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
     uint32_t stride;           // table pairs per chunk = chunk_bytes / 4
     uint32_t warm;             // iterations of run-in before a chunk (Plan::q1_warm)
+    uint32_t parts;            // threads that share one chunk (>= 1)
     float esr;
 };
 

@@ -1218,18 +1218,27 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
 // below 2^-26 twice over and the float sequence has locked onto the reference's), then through
 // its own chunk, writing the offsets every iteration starts from.  -ffp-contract=off: the
 // reference's generic build rounds the sum, the product and the update separately.
+// A long chunk is shared by `parts` threads (a.parts: each replays its own run-in and then its
+// piece of the chunk's iterations), so that the longest dependent chain is about warm + T / parts.
 __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
-    const uint64_t c = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t id = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
+    const uint64_t c = id / a.parts;
+    const uint32_t part = (uint32_t) (id - c * a.parts);
     if (c >= total) return;
     const uint64_t T = a.chunk_bytes >> 2;  // iterations of a full chunk
+    const uint64_t len = c < a.n_chunks ? a.chunk_bytes : a.tail_bytes;
+    const uint64_t Tc = len >> 2;           // iterations of this chunk
+    const uint64_t per = ((Tc + a.parts - 1) / a.parts + 7) & ~(uint64_t) 7;   // iterations per part, whole 16-byte blocks
+    const uint64_t p0 = (uint64_t) part * per, p1 = p0 + per < Tc ? p0 + per : Tc;
+    if (p0 >= Tc) return;
     float off0, off1;
     uint64_t cc = 0, t0 = 0;                // where the run-in starts: chunk, iteration
-    if (c * T <= (uint64_t) a.warm) {
+    if (c * T + p0 <= (uint64_t) a.warm) {
         off0 = a.carry_in[0];
         off1 = a.carry_in[1];
     } else {
-        const uint64_t g = c * T - a.warm;
+        const uint64_t g = c * T + p0 - a.warm;
         cc = g / T;
         t0 = g - cc * T;
         off0 = off1 = 127.5f;
@@ -1280,9 +1289,9 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         while (t < t1) single();
     };
     for (; cc < c; ++cc, t0 = 0) run(a.in + cc * a.chunk_bytes, a.chunk_bytes, t0, T, nullptr);
-    const uint64_t len = c < a.n_chunks ? a.chunk_bytes : a.tail_bytes;
-    run(a.in + c * a.chunk_bytes, len, 0, len >> 2, reinterpret_cast<float2 *>(a.table) + c * a.stride);
-    if (c == total - 1) {
+    if (t0 < p0) run(a.in + c * a.chunk_bytes, len, t0, p0, nullptr);   // the run-in's last stretch lies in this chunk
+    run(a.in + c * a.chunk_bytes, len, p0, p1, reinterpret_cast<float2 *>(a.table) + c * a.stride);
+    if (c == total - 1 && p1 == Tc) {
         a.carry_out[0] = off0;
         a.carry_out[1] = off1;
     }
@@ -1453,7 +1462,7 @@ int launch_tiny(const TinyLaunch &a, int conditioning, uint32_t threads, void *s
 
 int launch_offsets(const OffsetLaunch &a, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
+    const uint64_t total = (a.n_chunks + (a.tail_bytes ? 1 : 0)) * a.parts;
     if (total == 0) return 0;
     hipLaunchKernelGGL(correct_iq_offsets, dim3((uint32_t) ((total + 63) / 64)), dim3(64), 0, s, a);
     return hip_ok(hipGetLastError());
