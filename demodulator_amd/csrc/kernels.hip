@@ -16,12 +16,15 @@
 //              the chunk (partial sections, overflow pollution; SURVEY.md
 //              Appendix A.4), one output per lane (chunk_head).
 // demod_heads  the same replay, one thread per chunk, for what chunk_head does
-//              not cover: more than 4 sections, -q2 in front of -L, and the
-//              chunks of a bounds-checked (ragged) launch.
+//              not cover: more than 4 sections, -q2 in front of -L, chunks below
+//              256 KiB (where a kernel of its own is cheaper) and the chunks of a
+//              bounds-checked (ragged) launch.
 // demod_tiny   literal whole-chunk path for chunks shorter than one row.
+// correct_iq_offsets   -q1: the running DC offsets of correctIq, replayed per chunk
+//              after a run-in, into a table the other kernels subtract from the bytes.
 //
 // Reference semantics restated here (never copied):
-//   unpack         /root/reference/src/matrix.c:82-98, :100-118
+//   unpack         /root/reference/src/matrix.c:82-98, :100-118, :120-140
 //   discriminator  src/matrix.c:159-176
 //   filters        src/filter.c:212-231 (real), :233-259 (complex)
 //   chunk loop     src/matrix.c:236-273
