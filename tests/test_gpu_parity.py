@@ -685,3 +685,31 @@ def test_correct_iq_q1(orc, kw, n_bytes):
             t.join(timeout=120)
             assert not t.is_alive()
             assert np.array_equal(np.concatenate(parts).view(np.uint32), whole.view(np.uint32))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), C3, dict(lowpass_in=12500.0, lowpass_out=6500.0, in_degree=8, out_degree=7),
+    dict(lowpass_in=9600.0, in_degree=5, out_degree=2, mode=0x13), dict(mode=0x18), dict(mode=0x1C, lowpass_in=12500.0),
+    dict(out_degree=1), dict(lowpass_in=12500.0, in_degree=1, out_degree=8),
+], ids=["c2", "c3", "D8d7", "cheby_D5d2", "q2", "q3_L", "d1", "D1d8"])
+def test_chunk_heads_in_the_streaming_kernel_equal_the_head_kernel(kw):
+    """The first outputs of every chunk are replayed literally either by the wavefront that owns
+    the chunk's first row (chunk_head: one output per lane) or by the demod_heads kernel (one
+    thread per chunk): the reference's operations on the reference's values both ways, so every
+    bit agrees -- for every chunk size from one row up, ragged tails and int16 output included,
+    and whatever demod_set_head_mode(-1) picks."""
+    import torch
+    for B in (1024, 2048, 4096, 65536, 262144):
+        opt = dm.Options(buf_size=B, **kw)
+        n = 9 * B + 3 * 1024 + 40
+        iq = torch.from_numpy(oracle.synth_bytes(0xAB + B, 0, n)).cuda()
+        for fmt in ("f32", "s16"):
+            outs = []
+            for mode in (0, 1, -1):
+                with dm.Demodulator(opt) as d:
+                    d.set_head_mode(mode)
+                    if fmt == "s16":
+                        d.set_output_format("s16", 0.05)
+                    outs.append(d.process(iq).cpu().numpy())
+            raw = [o.view(np.uint8) for o in outs]      # bytes, so that -0.0 and +0.0 count as different
+            assert np.array_equal(raw[0], raw[1]) and np.array_equal(raw[0], raw[2]), (B, fmt)
