@@ -13,6 +13,11 @@
 
 #include "ctx.h"
 
+#ifndef DEMOD_Q1_THREADS
+#define DEMOD_Q1_THREADS 16384   // threads of correct_iq_offsets that fill the chip for its purposes (see run_offsets)
+#endif
+
+
 using namespace demod;
 
 namespace {
@@ -299,8 +304,17 @@ static int run_offsets(demod_ctx *ctx, const uint8_t *d_in, uint64_t n_bytes, ui
     o.tail_bytes = (uint32_t) (n_bytes - o.n_chunks * B);
     o.stride = (uint32_t) (B / 4);
     o.warm = pl.q1_warm;
-    // pieces of at least 4096 iterations: beyond that the run-in, which every piece repeats, is the chain
-    o.parts = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(16, (B / 4) / 4096));
+    // Every thread repeats the run-in before what it writes, so more threads shorten the chain
+    // only down to the run-in's own length, and they multiply the work -- 16-byte requests to 64
+    // different cache lines per load instruction, paid for in the CU's address unit.  A budget
+    // of DEMOD_Q1_THREADS threads: long chunks are shared by `parts` threads (pieces of at least
+    // 4096 iterations), short ones walked through `group` at a time by one thread.
+    const uint64_t chunks = o.n_chunks + (o.tail_bytes ? 1 : 0);
+    o.parts = o.group = 1;
+    if (chunks >= DEMOD_Q1_THREADS)
+        o.group = (uint32_t) ((chunks + DEMOD_Q1_THREADS - 1) / DEMOD_Q1_THREADS);
+    else
+        o.parts = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>({256, (B / 4) / 4096, DEMOD_Q1_THREADS / std::max<uint64_t>(1, chunks)}));
     o.esr = pl.esr;
     if (launch_offsets(o, stream)) {
         ctx->fail(DEMOD_E_HIP, "correct_iq_offsets launch", hipGetLastError());

@@ -93,7 +93,7 @@ struct TinyLaunch {
     uint32_t q1_stride;
 };
 
-// -q1: replay of correctIq's offset recurrence (src/matrix.c:131-138), one thread per chunk.
+// -q1: replay of correctIq's offset recurrence (src/matrix.c:131-138), a fixed budget of threads.
 struct OffsetLaunch {
     const uint8_t *in;         // first chunk
     float *table;              // out: (re, im) offsets BEFORE every iteration, stride pairs per chunk
@@ -104,7 +104,8 @@ struct OffsetLaunch {
     uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
     uint32_t stride;           // table pairs per chunk = chunk_bytes / 4
     uint32_t warm;             // iterations of run-in before a chunk (Plan::q1_warm)
-    uint32_t parts;            // threads that share one chunk (>= 1)
+    uint32_t parts;            // threads that share one chunk (>= 1) ...
+    uint32_t group;            // ... or chunks one thread walks through (>= 1; one of the two is 1)
     float esr;
 };
 

@@ -20,7 +20,7 @@
 //              256 KiB (where a kernel of its own is cheaper) and the chunks of a
 //              bounds-checked (ragged) launch.
 // demod_tiny   literal whole-chunk path for chunks shorter than one row.
-// correct_iq_offsets   -q1: the running DC offsets of correctIq, replayed per chunk
+// correct_iq_offsets   -q1: the running DC offsets of correctIq, replayed piece by piece
 //              after a run-in, into a table the other kernels subtract from the bytes.
 //
 // Reference semantics restated here (never copied):
@@ -1208,33 +1208,56 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
 }
 
 // ---------------------------------------------------------------------------
-// -q1: the running offsets of correctIq (one thread per chunk)
+// -q1: the running offsets of correctIq
 // ---------------------------------------------------------------------------
 // correctIq (src/matrix.c:120-140) walks a chunk from both ends: iteration t corrects complex
 // samples t and K-1-t with the offsets it finds and then moves them,
 //     off += ((byte[t] - off) + (byte[K-1-t] - off)) * esr        (re and im lanes alike),
 // and its static offsets carry on from chunk to chunk: a float recurrence over the whole stream,
 // every step rounded, so it cannot be re-associated.  It contracts, though -- a start value is
-// forgotten at the rate (1 - 2 esr) per iteration -- so each chunk's thread replays the literal
-// operations over the `warm` iterations BEFORE its chunk (from the call's carried-in state when
-// they reach that far back, from an arbitrary value otherwise: by then its influence has shrunk
-// below 2^-26 twice over and the float sequence has locked onto the reference's), then through
-// its own chunk, writing the offsets every iteration starts from.  -ffp-contract=off: the
-// reference's generic build rounds the sum, the product and the update separately.
-// A long chunk is shared by `parts` threads (a.parts: each replays its own run-in and then its
-// piece of the chunk's iterations), so that the longest dependent chain is about warm + T / parts.
+// forgotten at the rate (1 - 2 esr) per iteration -- so a thread replays the literal operations
+// over the `warm` iterations BEFORE the piece of the stream it writes (from the call's
+// carried-in state when they reach that far back, from an arbitrary value otherwise: by then
+// its influence has shrunk below 2^-26 twice over and the float sequence has locked onto the
+// reference's), then through its piece, writing the offsets every iteration starts from.
+// -ffp-contract=off: the reference's generic build rounds the sum, the product and the update
+// separately.  A piece is a part of a long chunk (a.parts threads share the chunk) or a.group
+// whole chunks: the host deals the stream out to a fixed budget of threads (api.cpp
+// run_offsets), the longest dependent chain is about warm + the piece.
+constexpr int kQ1Span = 64;  // iterations per span: 8 pairs of 16-byte loads, one from each end of the chunk
+
+struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t x, y, z, w; };  // a chunk's far end need not be 16-byte aligned
+
+// Where a thread is in the stream: chunk `cc` (at `chunk`, `len` bytes), iteration `t` of it.
+struct Q1Pos {
+    const uint8_t *chunk;
+    uint64_t len, t, cc;
+};
+
 __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
     const uint64_t id = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
-    const uint64_t c = id / a.parts;
-    const uint32_t part = (uint32_t) (id - c * a.parts);
+    // what this thread writes: from iteration p0 of chunk c to iteration p1 of chunk c_last
+    // (a piece of one chunk when chunks are shared, a.parts > 1; a.group whole chunks otherwise)
+    const uint64_t c = a.parts > 1 ? id / a.parts : id * a.group;
+    const uint32_t part = a.parts > 1 ? (uint32_t) (id - c * a.parts) : 0u;
     if (c >= total) return;
+    const uint64_t c_last = a.parts > 1 ? c : (c + a.group < total ? c + a.group : total) - 1;
     const uint64_t T = a.chunk_bytes >> 2;  // iterations of a full chunk
-    const uint64_t len = c < a.n_chunks ? a.chunk_bytes : a.tail_bytes;
+    auto bytes_of = [&](uint64_t chunk) -> uint64_t { return chunk < a.n_chunks ? a.chunk_bytes : a.tail_bytes; };
+    const uint64_t len = bytes_of(c);
     const uint64_t Tc = len >> 2;           // iterations of this chunk
-    const uint64_t per = ((Tc + a.parts - 1) / a.parts + 7) & ~(uint64_t) 7;   // iterations per part, whole 16-byte blocks
-    const uint64_t p0 = (uint64_t) part * per, p1 = p0 + per < Tc ? p0 + per : Tc;
+    // Chunks of whole spans (256 bytes and more) take the span-wise path below: every thread of a
+    // wavefront then runs the same instructions over its own bytes from the first iteration of its
+    // run-in to its last one -- run-in and piece are cut in whole spans -- whichever chunk
+    // boundaries it crosses on the way.  (Round 2's first form walked chunk by chunk: threads
+    // that crossed at different times took turns, 124k iterations of wavefront time for 67k.)
+    const bool spans = (T % kQ1Span) == 0 && (a.warm % kQ1Span) == 0 && (((uintptr_t) a.in) & 15u) == 0;
+    const uint64_t grain = spans ? (uint64_t) kQ1Span : 8u;
+    const uint64_t per = ((Tc + a.parts - 1) / a.parts + grain - 1) / grain * grain;  // iterations per part
+    const uint64_t p0 = (uint64_t) part * per;
     if (p0 >= Tc) return;
+    const uint64_t p1 = c_last > c ? bytes_of(c_last) >> 2 : (p0 + per < Tc ? p0 + per : Tc);
     float off0, off1;
     uint64_t cc = 0, t0 = 0;                // where the run-in starts: chunk, iteration
     if (c * T + p0 <= (uint64_t) a.warm) {
@@ -1246,25 +1269,40 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         t0 = g - cc * T;
         off0 = off1 = 127.5f;
     }
+    // (off0, off1) as one packed pair: v_pk_add_f32 / v_pk_mul_f32 round each element exactly as
+    // the scalar operations do; a wavefront alone pays ~9 cycles per dependent operation either
+    // way (tools/microbench/chain_latency.hip), the packed form has fewer instructions beside them
+    pf2 off = {off0, off1};
+    const pf2 esr2 = {a.esr, a.esr};
     auto update = [&](uint32_t fb0, uint32_t fb1, uint32_t mb0, uint32_t mb1) {
-        const float f0 = (float) fb0 - off0, m0 = (float) mb0 - off0;
-        const float f1 = (float) fb1 - off1, m1 = (float) mb1 - off1;
-        off0 += (f0 + m0) * a.esr;
-        off1 += (f1 + m1) * a.esr;
+        const pf2 f = pf2{(float) fb0, (float) fb1} - off;
+        const pf2 m = pf2{(float) mb0, (float) mb1} - off;
+        off = off + (f + m) * esr2;
     };
     auto byte_of = [](const uint4 &v, int i) -> uint32_t {
         const uint32_t w = i < 4 ? v.x : i < 8 ? v.y : i < 12 ? v.z : v.w;
         return (w >> (8 * (i & 3))) & 0xFFu;
     };
-    // iterations [t0, t1) of a chunk of `len` bytes; `row` (or null) receives the offsets every
-    // iteration starts from.  Eight iterations per pair of 16-byte loads where alignment allows
-    // (the thread is alone with a long dependent chain: the loads must not be on it), the next
-    // pair requested before the current one is worked through.
+    // eight iterations from one 16-byte block of each end; `row` (or null) receives the offsets
+    // every iteration starts from
+    // (row is 16-byte aligned here: two iterations' offsets leave as one store -- the stores go to
+    // 64 different cache lines per instruction, and there are as few of them as the data allows)
+    auto block = [&](const uint4 &f, const uint4 &m, float2 *row) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const pf2 before = off;
+            update(byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
+            if (row) *reinterpret_cast<float4 *>(row + j) = make_float4(before.x, before.y, off.x, off.y);
+            update(byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
+        }
+    };
+    // iterations [t0, t1) of a chunk, any alignment, any length: the path of chunks below 256
+    // bytes and of what a stream's last chunk has beyond its whole spans
     auto run = [&](const uint8_t *chunk, uint64_t len, uint64_t t0, uint64_t t1, float2 *row) {
         uint64_t t = t0;
         auto single = [&]() {
             const uint8_t *f = chunk + 2 * t, *m = chunk + len - 2 * t - 2;
-            if (row) row[t] = make_float2(off0, off1);
+            if (row) row[t] = make_float2(off.x, off.y);
             update(f[0], f[1], m[0], m[1]);
             ++t;
         };
@@ -1275,15 +1313,10 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
                 uint4 f = *reinterpret_cast<const uint4 *>(chunk + 2 * t);
                 uint4 m = *reinterpret_cast<const uint4 *>(chunk + len - 2 * t - 16);
                 for (; t + 8 <= t1; t += 8) {
-                    const bool more = t + 16 <= t1;
-                    const uint64_t tn = more ? t + 8 : t;
+                    const uint64_t tn = t + 16 <= t1 ? t + 8 : t;  // one block ahead
                     const uint4 fn = *reinterpret_cast<const uint4 *>(chunk + 2 * tn);
                     const uint4 mn = *reinterpret_cast<const uint4 *>(chunk + len - 2 * tn - 16);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (row) row[t + j] = make_float2(off0, off1);
-                        update(byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
-                    }
+                    block(f, m, row ? row + t : nullptr);
                     f = fn;
                     m = mn;
                 }
@@ -1291,12 +1324,80 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         }
         while (t < t1) single();
     };
-    for (; cc < c; ++cc, t0 = 0) run(a.in + cc * a.chunk_bytes, a.chunk_bytes, t0, T, nullptr);
-    if (t0 < p0) run(a.in + c * a.chunk_bytes, len, t0, p0, nullptr);   // the run-in's last stretch lies in this chunk
-    run(a.in + c * a.chunk_bytes, len, p0, p1, reinterpret_cast<float2 *>(a.table) + c * a.stride);
-    if (c == total - 1 && p1 == Tc) {
-        a.carry_out[0] = off0;
-        a.carry_out[1] = off1;
+    float2 *const table = reinterpret_cast<float2 *>(a.table);
+    if (!spans) {
+        for (; cc < c; ++cc, t0 = 0) run(a.in + cc * a.chunk_bytes, a.chunk_bytes, t0, T, nullptr);
+        if (t0 < p0) run(a.in + c * a.chunk_bytes, len, t0, p0, nullptr);   // the run-in's last stretch lies in this chunk
+        for (uint64_t w = c; w <= c_last; ++w)
+            run(a.in + w * a.chunk_bytes, bytes_of(w), w == c ? p0 : 0, w == c_last ? p1 : T, table + w * a.stride);
+    } else {
+        // The thread is alone with a long dependent chain, so nothing but the arithmetic may be
+        // on it: a span's 16 loads are requested while the span before it is worked through
+        // (one pair of loads ahead left the chain waiting ~1 us for every pair), into register
+        // sets that take turns, with no branch between a request and its use (hipcc would sink
+        // the loads to the use).
+        auto request = [&](const Q1Pos &p, uint4 (&f)[8], uint4 (&m)[8]) {
+            const uint4 *fp = reinterpret_cast<const uint4 *>(p.chunk + 2 * p.t);
+            const Unaligned16 *mp = reinterpret_cast<const Unaligned16 *>(p.chunk + p.len - 2 * p.t - 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f[j] = fp[j];
+                const Unaligned16 u = mp[-j];
+                m[j] = make_uint4(u.x, u.y, u.z, u.w);
+            }
+        };
+        // the span after p: the next one of the chunk, or the first one of the next chunk (only
+        // chunks before this thread's last are ever finished here, and those are full ones)
+        auto after = [&](const Q1Pos &p) -> Q1Pos {
+            Q1Pos n = p;
+            n.t += kQ1Span;
+            if (n.t == T && p.cc < c_last) {
+                n.chunk += a.chunk_bytes;
+                n.cc = p.cc + 1;
+                n.len = bytes_of(n.cc);
+                n.t = 0;
+            }
+            return n;
+        };
+        Q1Pos cur{a.in + cc * a.chunk_bytes, bytes_of(cc), t0, cc};
+        auto phase = [&](auto write_tag, uint64_t left) {
+            constexpr bool kWrite = decltype(write_tag)::value;
+            if (left == 0) return;
+            auto work = [&](const uint4 (&f)[8], const uint4 (&m)[8], const Q1Pos &p) {
+                float2 *row = kWrite ? table + p.cc * a.stride + p.t : nullptr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) block(f[j], m[j], kWrite ? row + 8 * j : nullptr);
+            };
+            uint4 fa[8], ma[8], fb[8], mb[8];
+            request(cur, fa, ma);
+            while (left >= 2) {
+                const Q1Pos n1 = after(cur);
+                request(n1, fb, mb);
+                __builtin_amdgcn_sched_barrier(0);
+                work(fa, ma, cur);
+                const Q1Pos n2 = after(n1);
+                request(left > 2 ? n2 : n1, fa, ma);  // nothing beyond the phase is asked for (n1 again, dropped)
+                __builtin_amdgcn_sched_barrier(0);
+                work(fb, mb, n1);
+                cur = n2;
+                left -= 2;
+            }
+            if (left == 1) {
+                work(fa, ma, cur);
+                cur = after(cur);
+            }
+        };
+        const uint64_t start = cc * T + t0, first = c * T + p0, last = c_last * T + p1;  // in iterations of the whole stream
+        phase(std::false_type{}, (first - start) / kQ1Span);
+        const uint64_t whole = (last - first) / kQ1Span;
+        phase(std::true_type{}, whole);
+        // (what a stream's last chunk has beyond its whole spans)
+        if (first + whole * kQ1Span < last)
+            run(a.in + c_last * a.chunk_bytes, bytes_of(c_last), first + whole * kQ1Span - c_last * T, p1, table + c_last * a.stride);
+    }
+    if (c_last == total - 1 && p1 == (bytes_of(c_last) >> 2)) {
+        a.carry_out[0] = off.x;
+        a.carry_out[1] = off.y;
     }
 }
 
@@ -1465,7 +1566,8 @@ int launch_tiny(const TinyLaunch &a, int conditioning, uint32_t threads, void *s
 
 int launch_offsets(const OffsetLaunch &a, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint64_t total = (a.n_chunks + (a.tail_bytes ? 1 : 0)) * a.parts;
+    const uint64_t chunks = a.n_chunks + (a.tail_bytes ? 1 : 0);
+    const uint64_t total = a.parts > 1 ? chunks * a.parts : (chunks + a.group - 1) / a.group;
     if (total == 0) return 0;
     hipLaunchKernelGGL(correct_iq_offsets, dim3((uint32_t) ((total + 63) / 64)), dim3(64), 0, s, a);
     return hip_ok(hipGetLastError());

@@ -248,7 +248,7 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
             return false;
         }
         const double need = std::log(255.0 * 67108864.0) / -std::log1p(-decay);
-        plan.q1_warm = (uint32_t) std::min(2.0 * need + 64.0, 4.0e9);
+        plan.q1_warm = (uint32_t) (std::ceil(std::min(2.0 * need + 64.0, 4.0e9) / 64.0) * 64.0);  // whole spans of correct_iq_offsets
     }
     plan.prefilter = in_degree != 0 || iq_mode == 2;
     plan.in_separate = iq_mode == 2 && !cascade;

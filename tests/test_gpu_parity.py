@@ -641,7 +641,10 @@ def test_tiny_chunks_through_the_pipelined_host_paths(orc, flags, B):
     (dict(buf_size=1024, sample_rate=96000.0, out_degree=5), 300 * 1024 + 1024),       # one-row chunks: the carried state decides
     (dict(buf_size=64), 5000 * 64 + 20),                                               # chunks below one row (literal kernel)
     (dict(buf_size=4096, lowpass_in=9600.0, in_degree=6, out_degree=7, sample_rate=192000.0), 64 * 4096),  # 3-tap designs, slow decay
-], ids=["default", "L_16k", "1k_S96k_d5", "b64", "D6d7_S192k"])
+    (dict(buf_size=1024), 40000 * 1024 + 500),          # more chunks than threads: each thread walks through several (group mode)
+    (dict(buf_size=256), 20000 * 256 + 20),             # the same with chunks of exactly one span of iterations
+    (dict(buf_size=4 << 20), 2 * (4 << 20) + 70004),    # long chunks shared by 256 threads each, unaligned far end of the last one
+], ids=["default", "L_16k", "1k_S96k_d5", "b64", "D6d7_S192k", "many_1k", "many_256", "b4M"])
 def test_correct_iq_q1(orc, kw, n_bytes):
     """-q1 (src/matrix.c:120-140): the offsets are a float recurrence over the whole stream.  Its
     literal operations are replayed per chunk after a run-in (correct_iq_offsets), so the path
