@@ -25,7 +25,10 @@ namespace {
 std::mutex g_err_mutex;
 std::string g_create_error;
 
-constexpr uint32_t kTinyThreads = 8192;
+#ifndef DEMOD_TINY_THREADS
+#define DEMOD_TINY_THREADS 65536
+#endif
+constexpr uint32_t kTinyThreads = DEMOD_TINY_THREADS;  // threads of demod_tiny (a multiple of 64); each owns tiny_stride floats of scratch
 constexpr uint32_t kPieceRows = 1u << 21;       // rows per demod_rows launch (2 GiB of input)
 // chunk heads inside the streaming kernel for chunks of at least this many rows (below, the
 // demod_heads kernel is cheaper), see heads_are_fused()
@@ -329,15 +332,21 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     const Plan &pl = ctx->plan;
     const uint64_t stride = 6 * chunk_bytes + 3 * (4 * kMaxSections + 8);
     if (!ctx->tiny_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tiny_done, hipEventDisableTiming));
-    if (!ctx->tiny_work || ctx->tiny_stride < stride) {
+    // one scratch per thread, as many threads as the call has chunks (up to kTinyThreads, whole
+    // wavefronts): a hand-off of a few chunks does not pay for a long stream's scratch
+    const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
+    const uint32_t threads = (uint32_t) ((std::min<uint64_t>(total, kTinyThreads) + 63) / 64 * 64);
+    if (!ctx->tiny_work || ctx->tiny_stride < stride || ctx->tiny_threads < threads) {
         if (ctx->tiny_work) {
             HIP_TRY(ctx, hipDeviceSynchronize());  // an earlier launch may still be using it
             HIP_TRY(ctx, hipFree(ctx->tiny_work));
         }
         ctx->tiny_work = nullptr;
         ctx->tiny_pending = false;
-        HIP_TRY(ctx, hipMalloc((void **) &ctx->tiny_work, (size_t) kTinyThreads * stride * sizeof(float)));
+        ctx->tiny_threads = 0;
+        HIP_TRY(ctx, hipMalloc((void **) &ctx->tiny_work, (size_t) threads * stride * sizeof(float)));
         ctx->tiny_stride = stride;
+        ctx->tiny_threads = threads;
     }
     // the scratch is shared: wait for the previous literal launch, whatever stream it ran on
     if (ctx->tiny_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->tiny_done, 0));
@@ -355,8 +364,6 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     t.out_scale = ctx->out_scale;
     t.q1_table = q1_table;
     t.q1_stride = q1_stride;
-    const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
-    const uint32_t threads = (uint32_t) std::min<uint64_t>(total, kTinyThreads);
     if (launch_tiny(t, pl.conditioning, threads, stream)) {
         ctx->fail(DEMOD_E_HIP, "demod_tiny launch", hipGetLastError());
         return DEMOD_E_HIP;

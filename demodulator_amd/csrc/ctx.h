@@ -34,11 +34,12 @@ struct demod_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
 
-    // scratch for the whole-chunk literal path (chunks < 1 KiB): ONE buffer, thread t
-    // always uses work + t * stride, so launches on different streams (the host path's
+    // scratch for the whole-chunk literal path (chunks < 1 KiB): ONE buffer, wavefront w's
+    // threads always use work + w * 64 * stride (interleaved), so launches on different streams (the host path's
     // stages) are ordered through tiny_done: each waits for the one before it
     float *tiny_work = nullptr;
     uint64_t tiny_stride = 0;
+    uint32_t tiny_threads = 0;   // threads the scratch has room for
     hipEvent_t tiny_done = nullptr;
     bool tiny_pending = false;
 

@@ -1123,12 +1123,21 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
 // ---------------------------------------------------------------------------
 constexpr uint32_t kTinyPad = 4 * kMaxSections + 8;
 
+// A thread's scratch, element i at p[64 i]: the 64 threads of a wavefront walk their buffers in
+// step, so element i of all of them is one 256-byte line (a region of its own per thread made
+// every access 64 separate transactions).
+struct TinyScratch {
+    float *p;
+    __device__ __forceinline__ float &operator[](uint64_t i) const { return p[i * 64u]; }
+    __device__ __forceinline__ TinyScratch operator+(uint64_t k) const { return TinyScratch{p + k * 64u}; }
+};
+
 template <int COND>
 __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
     const uint64_t tid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t) gridDim.x * blockDim.x;
     const uint64_t total = a.n_chunks + (a.tail_bytes ? 1 : 0);
-    float *F = a.work + tid * a.work_stride;
+    const TinyScratch F{a.work + (uint64_t) blockIdx.x * 64u * a.work_stride + threadIdx.x};
     const int Si = a.sec_in, So = a.sec_out;
 
     for (uint64_t c = tid; c < total; c += nthreads) {
@@ -1140,23 +1149,61 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
         // work = 2B floats (4B with the input filter) and a separate B-float
         // demod buffer; both padded so that the recurrences' reach past the
         // end (which the reference leaves to the heap) stays in zeroed scratch.
-        float *dem = F + 4 * a.chunk_bytes + kTinyPad;
-        for (uint64_t i = 0; i < a.work_stride; ++i) F[i] = 0.f;
-
+        const TinyScratch dem = F + 4 * a.chunk_bytes + kTinyPad;
         // -q2: the complex stage reads highpassDc's own buffer (zeros behind it)
         // and writes where the unpacked samples would otherwise be
         const bool pre = a.sec_pre > 0;  // -q2 in front of -L: highpassDc from its own buffer into F first
-        float *X = (a.in_separate || pre) ? dem + a.chunk_bytes + kTinyPad : F;
-        for (uint32_t i = 0; i < B; ++i) {
-            float v = unpack_byte<COND>(bytes[i], a.scale);
+        const bool x_apart = a.in_separate || pre;
+        const TinyScratch X = x_apart ? dem + a.chunk_bytes + kTinyPad : F;
+        // What the reference's calloc/memset leave at zero, as far as anything below reads it
+        // (the scratch is most of this kernel's memory traffic): the stages' outputs, which
+        // accumulate, and `reach` floats behind every buffer -- a stage with S sections reads
+        // 4 S - 1 floats past its input and output.  The samples' own B floats are overwritten.
+        {
+            const int smax = Si > So ? (Si > a.sec_pre ? Si : a.sec_pre) : (So > a.sec_pre ? So : a.sec_pre);
+            const uint32_t reach = 4u * (uint32_t) smax + 8u;
+            const uint32_t y2_at = (Si > 0 && !a.in_separate) ? 2u * B : B;  // where the output stage's cells start
+            for (uint32_t i = x_apart ? 0u : B; i < y2_at + Ld + reach; ++i) F[i] = 0.f;
+            for (uint32_t i = 0; i < Ld + reach; ++i) dem[i] = 0.f;
+            if (x_apart)
+                for (uint32_t i = B; i < B + reach; ++i) X[i] = 0.f;
+        }
+        auto sample = [&](uint32_t i, uint8_t byte) -> float {
+            float v = unpack_byte<COND>(byte, a.scale);
             if constexpr (COND == kCorrectIq) {
                 const float2 off = q1_offset(a.q1_table + 2ull * c * a.q1_stride, (int) (i >> 1), (int) (B >> 1));
                 v = v - ((i & 1u) ? off.y : off.x);
             }
-            X[i] = v;
+            return v;
+        };
+        // without a complex stage the samples go straight into the discriminator: no trip
+        // through the scratch (the stages are what has to be literal, this is element by element)
+        const bool direct = Si == 0 && !pre;
+        const bool words = (((uintptr_t) bytes) & 3u) == 0;  // (chunks are whole words: four bytes per request)
+        if (direct) {
+            for (uint32_t n = 0; n < Ld; ++n) {
+                float v[4];
+                if (words) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(bytes + 4 * n);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) v[j] = sample(4 * n + j, (uint8_t) (w >> (8 * j)));
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) v[j] = sample(4 * n + j, bytes[4 * n + j]);
+                }
+                dem[n] = discriminate_literal(v[0], v[1], v[2], v[3]);
+            }
+        } else if (words) {
+            for (uint32_t i = 0; i + 4 <= B; i += 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(bytes + i);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) X[i + j] = sample(i + j, (uint8_t) (w >> (8 * j)));
+            }
+        } else {
+            for (uint32_t i = 0; i < B; ++i) X[i] = sample(i, bytes[i]);
         }
-        float *src = F;
-        float *y2 = F + B;
+        TinyScratch src = F;
+        TinyScratch y2 = F + B;
         if (pre) {
             for (uint32_t i = 0; i < B; i += 2) {
                 for (int m = 0; m < a.sec_pre; ++m) {
@@ -1171,7 +1218,7 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
             }
         }
         if (Si > 0) {
-            float *x = pre ? F : X, *y = a.in_separate ? F : F + B;  // -L: x[B + t] aliases y[t], exactly as in the reference
+            const TinyScratch x = pre ? F : X, y = a.in_separate ? F : F + B;  // -L: x[B + t] aliases y[t], exactly as in the reference
             for (uint32_t i = 0; i < B; i += 2) {
                 for (int m = 0; m < Si; ++m) {
                     const uint32_t n = i + 2 * Si + 2 * m;
@@ -1186,8 +1233,9 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
             src = y;
             y2 = y + B;
         }
-        for (uint32_t n = 0; n < Ld; ++n)
-            dem[n] = discriminate_literal(src[4 * n], src[4 * n + 1], src[4 * n + 2], src[4 * n + 3]);
+        if (!direct)
+            for (uint32_t n = 0; n < Ld; ++n)
+                dem[n] = discriminate_literal(src[4 * n], src[4 * n + 1], src[4 * n + 2], src[4 * n + 3]);
         for (uint32_t i = 0; i < Ld; ++i) {
             for (int m = 0; m < So; ++m) {
                 const uint32_t n = i + So + m;

@@ -332,10 +332,18 @@ typedef struct {
     size_t work_len;
 } scratch_t;
 
+/* With chunks of a few bytes and many sections the recurrences reach past these buffers
+ * (a stage with S sections touches 2S+1 cells -- 4S+3 floats for the complex one -- behind its
+ * last output): heap contents in the reference, i.e. undefined there.  The checker must not
+ * corrupt its own heap over it: SLACK zeroed floats behind each buffer (never part of work_len,
+ * so the per-chunk memset matches the reference's).  Parity is only defined where the reach
+ * stays inside the reference's own allocation; the tests keep to that. */
+#define SLACK (4 * 16 + 8)
+
 static int make_scratch(const plan_t *pl, scratch_t *s) {
     s->work_len = (pl->chunk << 1) << (pl->prefilter ? 1 : 0);
-    s->work = calloc(s->work_len, sizeof(float));
-    s->demod = calloc(pl->chunk, sizeof(float));
+    s->work = calloc(s->work_len + SLACK, sizeof(float));
+    s->demod = calloc(pl->chunk + SLACK, sizeof(float));
     s->hp = pl->highpass ? calloc(pl->chunk + HP_PAD, sizeof(float)) : NULL;
     return (s->work && s->demod && (s->hp || !pl->highpass)) ? 0 : -1;
 }

@@ -633,6 +633,26 @@ def test_tiny_chunks_through_the_pipelined_host_paths(orc, flags, B):
             _check("process_host 40 MiB B=64", d.process_host(big), orc.process(fl, big, threads=_oracle_threads()), opt, big)
 
 
+@pytest.mark.parametrize("kw,B", [
+    (dict(mode=0x18), 16),                                                        # -q2: the complex stage reads a buffer of its own
+    (dict(mode=0x18, lowpass_in=12500.0, lowpass_out=6500.0), 64),                # -q2 in front of -L
+    (dict(lowpass_in=9000.0, in_degree=8, out_degree=8), 128),                    # four sections per stage: the longest reach past a buffer
+    (dict(out_degree=16), 64),                                                    # eight sections: the first eight of the sixteen outputs are never written
+    (dict(mode=0x1C, lowpass_in=12500.0, lowpass_out=6500.0), 512),               # -q3, the largest chunk of this kernel
+], ids=["q2_b16", "q2_L_b64", "D8d8_b128", "d16_b64", "q3_L_b512"])
+def test_tiny_chunks_more_chunks_than_threads(orc, kw, B):
+    """The literal kernel's threads take chunk after chunk with one scratch each, of which they
+    clear what the stages read beyond what they write: 80,000 chunks (more than there are
+    threads) and a short last one, twice in one context with different bytes -- anything left
+    over from an earlier chunk or call would show."""
+    opt = dm.Options(buf_size=B, **kw)
+    fl = oracle.Flags(**opt.__dict__)
+    with dm.Demodulator(opt) as d:
+        for seed in (0x7301, 0x7302):
+            data = oracle.synth_bytes(seed + B, 0, 80000 * B + (B // 2 if B >= 8 else 0))
+            _check(f"tiny {kw} B={B} seed {seed:#x}", d.process_host(data), orc.process(fl, data, threads=_oracle_threads()), opt, data)
+
+
 # -- -q1 correctIq: running offsets, carried from chunk to chunk and from call to call ----------
 
 @pytest.mark.parametrize("kw,n_bytes", [
