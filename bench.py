@@ -30,7 +30,9 @@ the votes run over a gloo control group.
 
 The RCCL point-to-point path is health-checked first in throw-away child
 processes (demodulator_amd/sharding.py::run_probe_child): a probe that hangs is
-killed from outside and this process never holds a stuck communicator.  If the
+killed from outside and this process never holds a stuck communicator.  The
+ranks make their first GPU call only after the probe's processes have gone: never
+more than one process of this benchmark per GPU at a time.  If the
 probe does not pass on every rank, the run still measures and prints the line
 for chunk-aligned cuts (no exchange), but says `"halo_exchange": "failed"` at
 top level and EXITS NON-ZERO: a line produced that way has not exercised the
@@ -265,14 +267,14 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    if torch.cuda.device_count() == 0:   # (counting devices does not initialise the GPU)
         raise SystemExit("bench.py needs an MI355X: the demodulation path has no CPU fallback")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     # DEMOD_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
     # (ranks share devices, the 64-byte halos travel through host memory); never for reported numbers
     backend = os.environ.get("DEMOD_BENCH_BACKEND", "nccl")
     data_group = None
     halo_exchange = "none (1 GPU)" if world == 1 else "none (chunk-aligned cuts)"
+    probe_ok = False
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # control plane (barriers, the max over ranks, the votes) on gloo;
@@ -286,32 +288,41 @@ def main() -> int:
 
         if not args.aligned:
             # 1. health check in throw-away processes with a rendezvous of their own: a hang
-            #    is killed from outside, this process makes no RCCL call before it has passed
+            #    is killed from outside, this process makes no RCCL call before it has passed --
+            #    and no GPU call at all: while the probe runs its processes are the only ones of
+            #    ours on the GPUs (one per device), and they are gone before the ranks arrive
             from demodulator_amd.sharding import run_probe_child
 
             port = [_free_port() if rank == 0 else 0]
             dist.broadcast_object_list(port, src=0)
             ok = run_probe_child(backend, rank, world, local_rank, port[0], args.probe_timeout,
                                  force_fail=os.environ.get("DEMOD_BENCH_FORCE_PROBE_FAIL") == "1")
-            ok = all_agree(ok)
-            # 2. the communicator of this process; every rank votes on the outcome, so that all
-            #    of them cut the stream the same way
-            if ok and backend == "nccl":
-                try:
-                    data_group = dist.new_group(backend="nccl")
-                    dist.all_reduce(torch.zeros(1, device="cuda"), group=data_group)  # communicator exists
-                    torch.cuda.synchronize()                                          # before any send/recv
-                    mine = True
-                except Exception as e:  # noqa: BLE001
-                    sys.stderr.write(f"[rank {rank}] RCCL group: {e!r}\n")
-                    mine = False
-                ok = all_agree(mine)
-            if ok:
-                halo_exchange = "rccl send/recv" if backend == "nccl" else f"{backend} send/recv (rehearsal)"
-            else:
-                halo_exchange = "failed"
-                data_group = None
-                args.aligned = True   # still measure: chunk-aligned cuts need no exchange
+            probe_ok = all_agree(ok)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the demodulation path has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+
+    if world > 1 and not args.aligned:
+        # 2. the communicator of this process; every rank votes on the outcome, so that all
+        #    of them cut the stream the same way
+        ok = probe_ok
+        if ok and backend == "nccl":
+            try:
+                data_group = dist.new_group(backend="nccl")
+                dist.all_reduce(torch.zeros(1, device="cuda"), group=data_group)  # communicator exists
+                torch.cuda.synchronize()                                          # before any send/recv
+                mine = True
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"[rank {rank}] RCCL group: {e!r}\n")
+                mine = False
+            ok = all_agree(mine)
+        if ok:
+            halo_exchange = "rccl send/recv" if backend == "nccl" else f"{backend} send/recv (rehearsal)"
+        else:
+            halo_exchange = "failed"
+            data_group = None
+            args.aligned = True   # still measure: chunk-aligned cuts need no exchange
 
     r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
                      args.segment_rows, args.prewarm_ms, data_group)

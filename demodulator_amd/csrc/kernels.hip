@@ -405,12 +405,30 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
     unpack_dword<COND, FOLD>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
     unpack_dword<COND, FOLD>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
     if constexpr (COND == kCorrectIq) {
+        // Sample k was corrected in iteration min(k, K-1-k) (q1_offset): a lane's 8 samples lie
+        // on one side of the chunk's middle whenever K is a multiple of 16, and their 8 offset
+        // pairs are then 64 consecutive bytes of the table, ascending in the first half,
+        // descending in the second: four 16-byte loads instead of eight 8-byte ones.
+        const int K = q1.K, k0 = q1.k0;
+        const bool first_half = k0 + 8 <= (K >> 1), second_half = k0 >= (K >> 1) && k0 + 8 <= K;
+        if ((K & 15) == 0 && (first_half || second_half)) {
+            const float4 *p = reinterpret_cast<const float4 *>(q1.table + 2 * (first_half ? k0 : K - 8 - k0));
+            const float4 t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+            const float offr[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z};
+            const float offi[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (q1.k0 + k < q1.K) {
-                const float2 off = q1_offset(q1.table, q1.k0 + k, q1.K);
-                xr[k] = xr[k] - off.x;
-                xi[k] = xi[k] - off.y;
+            for (int k = 0; k < 8; ++k) {
+                xr[k] = xr[k] - (first_half ? offr[k] : offr[7 - k]);
+                xi[k] = xi[k] - (first_half ? offi[k] : offi[7 - k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k0 + k < K) {
+                    const float2 off = q1_offset(q1.table, k0 + k, K);
+                    xr[k] = xr[k] - off.x;
+                    xi[k] = xi[k] - off.y;
+                }
             }
         }
     }
@@ -1540,8 +1558,9 @@ int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
 uint32_t max_segment_rows() { return (uint32_t) kGroup; }
 
 namespace {
-// -q1: the bounds-checked build with the zero-padded 5-tap stencils, whatever the design
-template <int TIN>
+// -q1: the bounds-checked build (its unpack reads the offsets table), with the stencil lengths of
+// the default designs or the zero-padded 5-tap stencils
+template <int TIN, int TOUT>
 int launch_rows_q1(const RowLaunch &a, hipStream_t s) {
     const uint32_t g0 = a.phase_rows, g1 = a.phase_rows + a.n_rows;
     const uint32_t segs = ((g1 + (1u << a.seg_log2) - 1u) >> a.seg_log2) - (g0 >> a.seg_log2);
@@ -1550,8 +1569,8 @@ int launch_rows_q1(const RowLaunch &a, hipStream_t s) {
     blocks = (blocks + DEMOD_XCD_INTERLEAVE - 1u) / DEMOD_XCD_INTERLEAVE * DEMOD_XCD_INTERLEAVE;
 #endif
     const dim3 threads(64 * kWavesPerBlock);
-    if (a.out_s16) hipLaunchKernelGGL((demod_rows<TIN, kMaxTaps, kCorrectIq, true, true>), dim3(blocks), threads, 0, s, a);
-    else hipLaunchKernelGGL((demod_rows<TIN, kMaxTaps, kCorrectIq, true, false>), dim3(blocks), threads, 0, s, a);
+    if (a.out_s16) hipLaunchKernelGGL((demod_rows<TIN, TOUT, kCorrectIq, true, true>), dim3(blocks), threads, 0, s, a);
+    else hipLaunchKernelGGL((demod_rows<TIN, TOUT, kCorrectIq, true, false>), dim3(blocks), threads, 0, s, a);
     return hip_ok(hipGetLastError());
 }
 }  // namespace
@@ -1559,7 +1578,11 @@ int launch_rows_q1(const RowLaunch &a, hipStream_t s) {
 int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.n_rows == 0) return 0;
-    if (conditioning == kCorrectIq) return taps_in == 0 ? launch_rows_q1<0>(a, s) : launch_rows_q1<kMaxTaps>(a, s);
+    if (conditioning == kCorrectIq) {
+        if (taps_in == 0 && taps_out == 2) return launch_rows_q1<0, 2>(a, s);
+        if (taps_in == 2 && taps_out == 2) return launch_rows_q1<2, 2>(a, s);
+        return taps_in == 0 ? launch_rows_q1<0, kMaxTaps>(a, s) : launch_rows_q1<kMaxTaps, kMaxTaps>(a, s);
+    }
     if (conditioning == kNormalize) return launch_rows_c<kNormalize>(a, taps_in, taps_out, s);
     if (conditioning == kShiftOriginPlain) return launch_rows_c<kShiftOriginPlain>(a, taps_in, taps_out, s);
     return launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s);
