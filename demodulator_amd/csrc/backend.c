@@ -92,18 +92,37 @@ struct writer {
 /* One thread writes: a second one on the same output file does not help -- writes to one
  * tmpfs/ext4 inode serialise on its lock (tried: two pwrite() halves per batch brought the
  * /dev/shm file -> file rate DOWN from 2.3 to 1.9 Gsamples/s, tools/host_path_rate.py). */
+static double seconds(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
+}
+
 static void *write_results(void *p) {
     struct writer *w = p;
     const size_t ob = (size_t) demod_output_bytes(w->dm);
+    const char *env = getenv("DEMOD_RING_STATS");
+    const int stats = env && env[0] == '1';
+    double waiting = 0, writing = 0, bytes = 0;
     for (;;) {
         const void *res = NULL;
         uint64_t n = 0;
+        const double t0 = stats ? seconds() : 0;
         if (demod_ring_collect(w->ring, &res, &n) != DEMOD_OK) die("collect", demod_last_error(w->dm));
         if (!n) break; /* the stream has ended and everything was handed out */
+        const double t1 = stats ? seconds() : 0;
         fwrite(res, ob, n, w->out);
+        if (stats) {
+            waiting += t1 - t0;
+            writing += seconds() - t1;
+            bytes += (double) ob * (double) n;
+        }
         if (demod_ring_release(w->ring) != DEMOD_OK) die("release", demod_last_error(w->dm));
     }
     fflush(w->out);
+    if (stats && writing > 0)
+        fprintf(stderr, "demod writer: %.3f s in fwrite (%.2f GB/s while writing), %.3f s waiting for results\n", writing,
+                bytes / writing / 1e9, waiting);
     return NULL;
 }
 
@@ -116,13 +135,18 @@ static void run_ring(demod_consumer_args *args, demod_ctx *dm, void *arena, size
     w.dm = dm;
     w.out = args->outFile;
     if (pthread_create(&wt, NULL, write_results, &w)) die("pthread_create", strerror(errno));
+    const char *env = getenv("DEMOD_RING_STATS");
+    const int stats = env && env[0] == '1';
+    double waiting = 0, handling = 0;
     for (;;) {
         size_t n;
         int flag;
+        const double t0 = stats ? seconds() : 0;
         if (wait_full(args)) {
             (void) demod_ring_commit(ring, 0, 1);
             break;
         }
+        const double t1 = stats ? seconds() : 0;
         pthread_mutex_lock(&args->mutex);
         n = args->bufSize;
         flag = args->exitFlag;
@@ -143,8 +167,14 @@ static void run_ring(demod_consumer_args *args, demod_ctx *dm, void *arena, size
         if (!flag) args->buf = demod_ring_input(ring); /* the producer's next fread goes here */
         pthread_mutex_unlock(&args->mutex);
         sem_post(args->empty);
+        if (stats) {
+            waiting += t1 - t0;
+            handling += seconds() - t1;
+        }
         if (flag) break;
     }
+    if (stats)
+        fprintf(stderr, "demod consumer: %.3f s waiting for hand-offs, %.3f s taking them (commit, next slot)\n", waiting, handling);
     pthread_join(wt, NULL);
     demod_ring_destroy(ring);
     /* the hand-off buffer is the backend's (allocateBuffer made it; the reference's CUDA
