@@ -163,8 +163,8 @@ int demod_set_seamless(demod_ctx *ctx, int on) {
 
 int demod_set_head_mode(demod_ctx *ctx, int mode) {
     if (!ctx) return DEMOD_E_INVAL;
-    if (mode < -1 || mode > 1) {
-        ctx->fail(DEMOD_E_INVAL, "head mode must be -1 (automatic), 0 (demod_heads kernel) or 1 (inside the streaming kernel)");
+    if (mode < -1 || mode > 2) {
+        ctx->fail(DEMOD_E_INVAL, "head mode must be -1 (automatic), 0 (head kernels), 1 (inside the streaming kernel) or 2 (thread-per-chunk head kernels only)");
         return DEMOD_E_INVAL;
     }
     ctx->head_mode = mode;
@@ -231,7 +231,7 @@ static bool heads_are_fused(const demod_ctx *ctx) {
     if (pl.conditioning == kCorrectIq) return false;  // -q1 runs in the bounds-checked build
     if (pl.head_quads == 0) return true;
     const bool can = pl.in.sections <= kFusedHeadSections && pl.out.sections <= kFusedHeadSections && pl.pre.sections == 0;
-    if (!can || ctx->head_mode == 0) return false;
+    if (!can || ctx->head_mode == 0 || ctx->head_mode == 2) return false;
     if (ctx->head_mode == 1) return true;
     const uint64_t rows_per_chunk = ctx->seamless ? (1ull << 31) : pl.chunk_bytes / kRowBytes;
     return rows_per_chunk >= kFusedMinRows;
@@ -589,6 +589,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         h.last_chunk_bytes = (uint32_t) std::min<uint64_t>((eos && last_len < B) ? last_len : B, 1u << 30);
         fill_sections(pl, h.sec_in, h.sec_out, h.sos_in, h.sos_out, h.scale, h.sec_pre, h.sos_pre);
         h.in_separate = pl.in_separate;
+        h.thread_per_head = ctx->head_mode == 2;
         if (q1) {
             h.q1_table = ctx->q1_table + 2ull * skip * q1_stride;  // (buffers start on a chunk boundary: head i is chunk i)
             h.q1_stride = q1_stride;

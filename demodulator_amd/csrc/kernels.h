@@ -69,6 +69,7 @@ struct HeadLaunch {
     float scale;
     const float *q1_table;     // -q1: offsets of head 0's chunk onwards (see RowLaunch), q1_stride pairs per chunk
     uint32_t q1_stride;
+    int thread_per_head;       // keep to the thread-per-chunk kernels (demod_set_head_mode 2: what the tests compare demod_heads_wave with)
 };
 
 // Whole-chunk literal kernel for chunks smaller than one row (B < 1024).

@@ -16,9 +16,11 @@
 //              the chunk (partial sections, overflow pollution; SURVEY.md
 //              Appendix A.4), one output per lane (chunk_head).
 // demod_heads  the same replay, one thread per chunk, for what chunk_head does
-//              not cover: more than 4 sections, -q2 in front of -L, chunks below
-//              256 KiB (where a kernel of its own is cheaper) and the chunks of a
-//              bounds-checked (ragged) launch.
+//              not cover: -q2 in front of -L, -q1, chunks below 256 KiB (where a
+//              kernel of its own is cheaper) and the chunks of a bounds-checked
+//              (ragged) launch.
+// demod_heads_wave  chunk_head with room for 8 sections per stage, one wavefront
+//              per chunk: designs of degree 9-16.
 // demod_tiny   literal whole-chunk path for chunks shorter than one row.
 // correct_iq_offsets   -q1: the running DC offsets of correctIq, replayed piece by piece
 //              after a run-in, into a table the other kernels subtract from the bytes.
@@ -612,7 +614,8 @@ __device__ __forceinline__ uint4 load_row16_ragged(const uint8_t *row_base, uint
 // complex cells 2n, 2n+1), walks m = S-1 .. 0 and fetches the neighbour's previous value
 // from lane n + 1: every lane runs the literal operations of its own cells, all at once.
 // Bit-identical to demod_heads (same operations on the same values).
-constexpr int kFusedSections = kFusedHeadSections;  // sections per stage chunk_head handles (degrees <= 8)
+constexpr int kFusedSections = kFusedHeadSections;  // sections per stage chunk_head handles inside demod_rows (degrees <= 8)
+constexpr int kWaveHeadSections = kMaxSections;     // ... and in a kernel of its own (demod_heads_wave: any degree)
 
 __device__ __forceinline__ float lane_read(float v, uint32_t src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int) (src_lane << 2), __float_as_int(v)));
@@ -625,8 +628,8 @@ __device__ __forceinline__ float section_update(const float (&row)[6], float cur
     return t - (row[3] + row[4] * x0 + row[5] * x1);
 }
 
-template <int COND, bool S16>
-__device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane) {
+template <int COND, bool S16, int MAXSEC = kFusedSections, class LAUNCH = RowLaunch>
+__device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane, uint32_t n_out) {
     // the segment's own stores (among them the interior-formula values of this row's first
     // lanes, which are overwritten below) are complete before anything here is stored
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -644,7 +647,7 @@ __device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *ch
         float cAr = 0.f, cAi = 0.f, cBr = 0.f, cBi = 0.f, pAr = 0.f, pAi = 0.f, pBr = 0.f, pBi = 0.f;
         const int cellA = 2 * (int) lane;
 #pragma unroll
-        for (int m = kFusedSections - 1; m >= 0; --m) {
+        for (int m = MAXSEC - 1; m >= 0; --m) {
             if (m < Si) {
                 const float nBr = from_next_lane(pAr, 0.f), nBi = from_next_lane(pAi, 0.f);  // cell 2n + 2 lives in the next lane
                 const float vAr = section_update<true>(a.sos_in[m], cAr, pBr, x0r, x1r);
@@ -670,7 +673,7 @@ __device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *ch
         const float zur = own ? ((lane & 1u) ? rA1 : rB1) : 0.f, zui = own ? ((lane & 1u) ? iA1 : iB1) : 0.f;
         float cr = 0.f, ci = 0.f, pr = 0.f, pi = 0.f;
 #pragma unroll
-        for (int m = kFusedSections - 1; m >= 0; --m) {
+        for (int m = MAXSEC - 1; m >= 0; --m) {
             if (m < Si) {
                 const float nr = from_next_lane(pr, 0.f), ni = from_next_lane(pi, 0.f);
                 const float vr = section_update<true>(a.sos_in[m], cr, nr, ztr, zur);
@@ -688,7 +691,7 @@ __device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *ch
     const float d1 = from_next_lane(d0, 0.f);
     float cy = y0, py = y0;  // P(n, So) = P(n, So + 1) = what the cell held before
 #pragma unroll
-    for (int m = kFusedSections - 1; m >= 0; --m) {
+    for (int m = MAXSEC - 1; m >= 0; --m) {
         if (m < So) {
             const float ny = from_next_lane(py, 0.f);
             const float v = section_update<true>(a.sos_out[m], cy, ny, d0, d1);
@@ -697,7 +700,7 @@ __device__ __forceinline__ void chunk_head(const RowLaunch &a, const uint8_t *ch
             cy = ex ? v : cy;
         }
     }
-    if (lane < 4u * a.head_quads) {
+    if (lane < n_out) {
         if constexpr (S16) __builtin_nontemporal_store(to_s16(cy, a.out_scale), reinterpret_cast<int16_t *>(a.out) + out_index + lane);
         else __builtin_nontemporal_store(cy, reinterpret_cast<float *>(a.out) + out_index + lane);
     }
@@ -937,11 +940,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
             if (a.fused_heads != 0u) {
                 for (uint32_t r = rb; r < re; ++r)
                     if (((g0 + r) & rpc_mask) == 0u)
-                        chunk_head<COND, S16>(a, a.in + (uint64_t) r * kRowBytes, (uint64_t) r * kRowOutputs, lane);
+                        chunk_head<COND, S16>(a, a.in + (uint64_t) r * kRowBytes, (uint64_t) r * kRowOutputs, lane, 4u * a.head_quads);
             }
         } else {
             if (a.fused_heads != 0u && (gs & rpc_mask) == 0u && gs >= g0)
-                chunk_head<COND, S16>(a, a.in + (uint64_t) rb * kRowBytes, (uint64_t) rb * kRowOutputs, lane);
+                chunk_head<COND, S16>(a, a.in + (uint64_t) rb * kRowBytes, (uint64_t) rb * kRowOutputs, lane, 4u * a.head_quads);
         }
     }
 }
@@ -1134,6 +1137,26 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
         if (a.out_s16) store_quad<true>(out_address<true>(a.out, out0 + n), q, a.out_scale);
         else store_quad<false>(out_address<false>(a.out, out0 + n), q, a.out_scale);
     }
+}
+
+// ---------------------------------------------------------------------------
+// chunk heads of designs with more than four sections per stage: one wavefront per head
+// ---------------------------------------------------------------------------
+// demod_heads<COND, -1, -1> keeps its cells in scratch memory, one thread per chunk: with a
+// few thousand chunks per dispatch that is one long latency chain (0.15 ms per 2^30 bytes of
+// default chunks at -L -D 9 -d 9).  chunk_head's lane-parallel replay has no such chain; here it
+// runs with room for kMaxSections sections, one wavefront per head.  Same operations on the same
+// values as the thread-per-chunk kernel (tests compare the two bit for bit).  Not for -q1 and
+// not with highpassDc in front of -L (chunk_head has neither); the chunk must hold the window
+// the 64 lanes read (264 bytes: every chunk of a whole row does).
+constexpr int kHeadWaves = 4;
+template <int COND, bool S16>
+__global__ __launch_bounds__(64 * kHeadWaves) void demod_heads_wave(const HeadLaunch a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t head = blockIdx.x * (uint32_t) kHeadWaves + (threadIdx.x >> 6);
+    if (head >= a.n_heads) return;
+    chunk_head<COND, S16, kWaveHeadSections, HeadLaunch>(a, a.in + (uint64_t) head * a.chunk_bytes,
+                                                         (uint64_t) head * (a.chunk_bytes >> 2), lane, a.head_outputs);
 }
 
 // ---------------------------------------------------------------------------
@@ -1606,6 +1629,28 @@ void launch_heads_c(const HeadLaunch &a, hipStream_t s) {
     DEMOD_HEADS_CASE(2, 1)
     DEMOD_HEADS_CASE(2, 2)
 #undef DEMOD_HEADS_CASE
+    // any other design: one wavefront per head where chunk_head covers the case (see
+    // demod_heads_wave), the thread-per-chunk replay with its cells in scratch for the rest --
+    // -q1, highpassDc in front of -L, a last chunk shorter than the lanes' window
+    if constexpr (COND != kCorrectIq) {
+        if (!a.thread_per_head && a.sec_pre == 0 && a.head_outputs <= 64u && a.chunk_bytes >= kRowBytes) {
+            const uint32_t by_wave = a.last_chunk_bytes >= kRowBytes ? a.n_heads : a.n_heads - 1u;
+            if (by_wave) {
+                HeadLaunch w = a;
+                w.n_heads = by_wave;
+                const dim3 grid((by_wave + kHeadWaves - 1u) / kHeadWaves), threads(64 * kHeadWaves);
+                if (a.out_s16) hipLaunchKernelGGL((demod_heads_wave<COND, true>), grid, threads, 0, s, w);
+                else hipLaunchKernelGGL((demod_heads_wave<COND, false>), grid, threads, 0, s, w);
+            }
+            if (by_wave == a.n_heads) return;
+            HeadLaunch t = a;  // the short last chunk's head
+            t.in = a.in + (uint64_t) by_wave * a.chunk_bytes;
+            t.out = static_cast<char *>(a.out) + (uint64_t) by_wave * (a.chunk_bytes >> 2) * (a.out_s16 ? 2u : 4u);
+            t.n_heads = 1;
+            hipLaunchKernelGGL((demod_heads<COND, -1, -1>), dim3(1), dim3(64), 0, s, t);
+            return;
+        }
+    }
     hipLaunchKernelGGL((demod_heads<COND, -1, -1>), dim3(blocks), dim3(64), 0, s, a);
 }
 }  // namespace

@@ -155,7 +155,8 @@ class Demodulator:
         return np.int16 if self._lib.demod_output_bytes(self._ctx) == 2 else np.float32
 
     def set_head_mode(self, mode: int) -> None:
-        """Where chunk heads are replayed: 1 inside the streaming kernel, 0 demod_heads kernel, -1 automatic."""
+        """Where chunk heads are replayed: 1 inside the streaming kernel, 0 head kernels, 2 thread-per-chunk head
+        kernels only, -1 automatic."""
         fn = getattr(self._lib, "demod_set_head_mode", None)
         if fn is not None:      # absent from older builds selected with DEMOD_HIP_LIBRARY
             self._check(fn(self._ctx, mode), "demod_set_head_mode")

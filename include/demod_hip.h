@@ -292,8 +292,10 @@ int demod_set_segment_rows(demod_ctx *ctx, uint32_t rows);
 
 /* Tuning knob: where the first outputs of every chunk (partial sections, overflow
  * cells; not interior) are replayed: 1 = by the wavefront of the streaming kernel that
- * owns the chunk's first row (one kernel per dispatch), 0 = by the demod_heads kernel
- * behind it, -1 = automatic by chunk size (default).  Results are bit-identical. */
+ * owns the chunk's first row (one kernel per dispatch), 0 = by a head kernel behind it
+ * (a thread per chunk for the default designs, a wavefront per chunk for designs with more
+ * than four sections per stage), 2 = as 0 but thread-per-chunk kernels only, -1 = automatic
+ * by chunk size (default).  Results are bit-identical. */
 int demod_set_head_mode(demod_ctx *ctx, int mode);
 
 /* Tuning knob: rows per dispatch of the fused kernel (a call covering more is

@@ -714,13 +714,16 @@ def test_correct_iq_q1(orc, kw, n_bytes):
     dict(), C3, dict(lowpass_in=12500.0, lowpass_out=6500.0, in_degree=8, out_degree=7),
     dict(lowpass_in=9600.0, in_degree=5, out_degree=2, mode=0x13), dict(mode=0x18), dict(mode=0x1C, lowpass_in=12500.0),
     dict(out_degree=1), dict(lowpass_in=12500.0, in_degree=1, out_degree=8),
-], ids=["c2", "c3", "D8d7", "cheby_D5d2", "q2", "q3_L", "d1", "D1d8"])
+    dict(lowpass_in=12500.0, lowpass_out=6500.0, in_degree=9, out_degree=9), dict(lowpass_in=9000.0, in_degree=16, out_degree=12),
+    dict(out_degree=16), dict(mode=0x1C, lowpass_in=12500.0, in_degree=11, out_degree=3), dict(mode=0x13, lowpass_in=9600.0, in_degree=10, out_degree=14),
+], ids=["c2", "c3", "D8d7", "cheby_D5d2", "q2", "q3_L", "d1", "D1d8", "D9d9", "D16d12", "d16", "q3_D11d3", "cheby_D10d14"])
 def test_chunk_heads_in_the_streaming_kernel_equal_the_head_kernel(kw):
     """The first outputs of every chunk are replayed literally either by the wavefront that owns
-    the chunk's first row (chunk_head: one output per lane) or by the demod_heads kernel (one
-    thread per chunk): the reference's operations on the reference's values both ways, so every
-    bit agrees -- for every chunk size from one row up, ragged tails and int16 output included,
-    and whatever demod_set_head_mode(-1) picks."""
+    the chunk's first row (chunk_head: one output per lane), by a wavefront of demod_heads_wave
+    (the same replay with room for eight sections per stage: mode 0 with more than four) or by
+    the demod_heads kernels (one thread per chunk: mode 2): the reference's operations on the
+    reference's values every way, so every bit agrees -- for every chunk size from one row up,
+    ragged tails and int16 output included, and whatever demod_set_head_mode(-1) picks."""
     import torch
     for B in (1024, 2048, 4096, 65536, 262144):
         opt = dm.Options(buf_size=B, **kw)
@@ -728,11 +731,11 @@ def test_chunk_heads_in_the_streaming_kernel_equal_the_head_kernel(kw):
         iq = torch.from_numpy(oracle.synth_bytes(0xAB + B, 0, n)).cuda()
         for fmt in ("f32", "s16"):
             outs = []
-            for mode in (0, 1, -1):
+            for mode in (2, 0, 1, -1):
                 with dm.Demodulator(opt) as d:
                     d.set_head_mode(mode)
                     if fmt == "s16":
                         d.set_output_format("s16", 0.05)
                     outs.append(d.process(iq).cpu().numpy())
             raw = [o.view(np.uint8) for o in outs]      # bytes, so that -0.0 and +0.0 count as different
-            assert np.array_equal(raw[0], raw[1]) and np.array_equal(raw[0], raw[2]), (B, fmt)
+            assert all(np.array_equal(raw[0], r) for r in raw[1:]), (B, fmt, [bool(np.array_equal(raw[0], r)) for r in raw[1:]])
