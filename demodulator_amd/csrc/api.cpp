@@ -335,6 +335,7 @@ static int run_tiny(demod_ctx *ctx, const uint8_t *d_in, uint64_t chunk_bytes, u
     // one scratch per thread, as many threads as the call has chunks (up to kTinyThreads, whole
     // wavefronts): a hand-off of a few chunks does not pay for a long stream's scratch
     const uint64_t total = n_chunks + (tail_bytes ? 1 : 0);
+    if (total == 0) return DEMOD_OK;
     const uint32_t threads = (uint32_t) ((std::min<uint64_t>(total, kTinyThreads) + 63) / 64 * 64);
     if (!ctx->tiny_work || ctx->tiny_stride < stride || ctx->tiny_threads < threads) {
         if (ctx->tiny_work) {
