@@ -307,6 +307,19 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
         err = "stencil longer than supported";
         return false;
     }
+    // The streaming kernel's shiftOrigin build hands the complex stencil 128 + sample and folds the
+    // -128 into the stencil's constant, -128 * sum(h) (one operation per sample less).  That constant
+    // is a float: where it is not exactly -128 * sum(h) -- L = 9600 Hz at 125 kS/s: off by half an ulp,
+    // 7.6e-6 -- every filtered sample carries the difference, and a filtered sample that comes out
+    // next to zero (|z| = 0.01 happens once in 1e10) turns by more than the reference's own builds
+    // differ there.  Such designs take the build that subtracts 128 from the samples instead
+    // (kShiftOriginPlain: 3.6 % slower); the BASELINE designs' constants are exact.
+    if (plan.conditioning == kShiftOrigin && plan.stencil_in.taps > 0) {
+        double sum = 0.0;
+        for (int j = 0; j < plan.stencil_in.taps; ++j) sum += (double) plan.stencil_in.h[j];
+        const double re = -128.0 * sum, im = (double) plan.stencil_in.bias_im - 128.0 * sum;  // exact in double: a few floats
+        if ((double) (float) re != re || (double) (float) im != im) plan.conditioning = kShiftOriginPlain;
+    }
 
     // Finite arithmetic is proven here, once, instead of being tested per output (see
     // plan_magnitude_bound): 1e30 leaves eight decades to FLT_MAX for the products' rounding.

@@ -32,7 +32,8 @@ Options options_from_params(const demod_params &p);
 // kShiftOriginPlain: the shiftOrigin unpack without folding its -128 into the complex
 // stencil's constant (kernels.hip, fold_unpack): the -q2 highpass taps (+3, -1) cancel for
 // samples with x[k+1] = 3 x[k], and there the result has to be as precise as the samples are
-// small, not as 128 + sample is.
+// small, not as 128 + sample is.  Also chosen for -q0 designs whose folded constant
+// -128 * sum(h) is not exactly a float (build_plan).
 // kCorrectIq (-q1): byte minus a running DC offset that the reference carries from sample pair to
 // sample pair and from chunk to chunk (src/matrix.c:120-140); the offsets are replayed by a
 // pass of their own into a table the other kernels read (kernels.hip, correct_iq_offsets).

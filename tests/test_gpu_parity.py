@@ -431,6 +431,87 @@ def test_random_option_sets_and_lengths(orc):
     assert n_cases >= min(30, rounds // 2)
 
 
+def test_ill_conditioned_sample_of_a_design_whose_folded_constant_is_inexact(orc):
+    """-L 9600 at 125 kS/s: taps 2.0430384, -0.6233514, whose folded unpack constant -128 * sum(h)
+    is half an ulp away from its float (7.6e-6).  Samples (18, -10), (59, -36) filter to
+    z = (-0.003, 0.010): the discriminator value there turns by error / |z|, and with the constant's
+    error in every filtered sample the streaming kernel was 1.7e-3 off where the reference's own two
+    builds differ by 1e-4 (found by test_random_call_patterns, seed 1).  Such designs take the build
+    that subtracts 128 from the samples (plan.cpp build_plan); planted here at several positions of
+    several chunks, heads and chunk ends included."""
+    opt = dm.Options(lowpass_in=9600.0, buf_size=16384)
+    data = oracle.synth_bytes(0xF01D, 0, 6 * 16384).copy()
+    for k in (3, 700, 1001, 4094, 8190, 8192 + 2047, 3 * 8192 + 5555):   # complex sample index of the first of the pair
+        data[2 * k:2 * k + 4] = (18 + 127, -10 + 127, 59 + 127, -36 + 127)
+    with dm.Demodulator(opt) as d:
+        got = d.process_host(data)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    _check("planted |z| = 0.01", got, want, opt, data)
+    # beyond the criterion: within a small multiple of what the reference's other build (FMA
+    # contraction) differs by at these outputs (1.06e-4; the folded form was at 1.7e-3)
+    fma = oracle.restatement_fma()
+    if fma is not None:
+        self_diff = np.abs(fma.process(oracle.Flags(**opt.__dict__), data) - want)
+        assert float(np.abs(got - want).max()) <= 4.0 * float(self_diff.max()) + 2e-5, (np.abs(got - want).max(), self_diff.max())
+
+
+def test_random_call_patterns(orc):
+    """Seeded sweep over HOW a stream reaches the path rather than over its options: one stream,
+    cut at random rows into several calls (each with its chunk offset and the 64 bytes that
+    follow it), random dispatch pieces, segment sizes, head modes and output formats.  However
+    it is cut, every bit equals the one-call result; the one-call float result is compared with
+    the oracle."""
+    import os
+    import torch
+    rounds = int(os.environ.get("DEMOD_FUZZ_CASES", "32"))
+    rng = np.random.default_rng(int(os.environ.get("DEMOD_FUZZ_SEED", "20261005")) + 77)
+    for _ in range(rounds):
+        with_in = bool(rng.integers(0, 2))
+        mode = 0x10 | int(rng.choice([0, 0, 1, 2, 3])) | int(rng.choice([0, 0, 0, 0x8, 0xC]))
+        B = int(1 << rng.integers(8, 18))
+        opt = dm.Options(sample_rate=float(rng.choice([96000.0, 125000.0])),
+                         lowpass_in=float(rng.choice([9600.0, 12500.0])) if with_in else 0.0,
+                         lowpass_out=float(rng.choice([6500.0, 12500.0])),
+                         in_degree=int(rng.choice([0, 0, int(rng.integers(1, 17))])) if with_in else 0,
+                         out_degree=int(rng.choice([3, 3, int(rng.integers(1, 17))])), mode=mode, buf_size=B)
+        try:
+            dm.design(opt)
+        except dm.DemodError:
+            continue
+        unit = 1024 if B >= 1024 else B                     # calls start on rows (whole chunks below one row)
+        n_units = int(rng.integers(2, max(3, min(6 * B, 1 << 20) // unit)))
+        n_bytes = n_units * unit + (int(rng.integers(0, unit)) & ~3 if rng.random() < 0.5 else 0)
+        data = rng.integers(0, 256, n_bytes, dtype=np.uint8)
+        iq = torch.from_numpy(data).cuda()
+        cuts = sorted({0, n_bytes, *(int(c) * unit for c in rng.integers(1, n_units, size=int(rng.integers(1, 5))))})
+        s16 = rng.random() < 0.3
+        outs = []
+        for whole in (True, False):
+            with dm.Demodulator(opt) as d:
+                d.set_head_mode(int(rng.choice([-1, 0, 1, 2])))
+                d.set_segment_rows(int(rng.choice([0, 1, 2, 4])))
+                d.set_piece_rows(int(rng.choice([0, 4, 16, 256])))
+                if s16:
+                    d.set_output_format("s16", 0.02)
+                if whole:
+                    outs.append(d.process(iq).cpu().numpy())
+                    continue
+                parts = []
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    last = b == n_bytes
+                    halo = None
+                    if not last:
+                        halo = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device="cuda")
+                        k = min(dm.HALO_BYTES, n_bytes - b)
+                        halo[:k] = iq[b:b + k]
+                    parts.append(d.process(iq[a:b].clone(), chunk_offset=a % B, halo=halo, end_of_stream=last))
+                torch.cuda.synchronize()
+                outs.append(torch.cat(parts).cpu().numpy())
+        assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8)), (opt, n_bytes, cuts, s16)
+        if not s16:
+            _check(f"{opt} n_bytes={n_bytes}", outs[0], orc.process(oracle.Flags(**opt.__dict__), data), opt, data)
+
+
 @pytest.mark.parametrize("flags", [C2, C3, dict(lowpass_in=12500.0, lowpass_out=6500.0, out_degree=7, in_degree=6)],
                          ids=["C2", "C3", "d7D6"])
 def test_seamless_mode_equals_one_long_chunk(orc, flags):
