@@ -455,6 +455,40 @@ def test_ill_conditioned_sample_of_a_design_whose_folded_constant_is_inexact(orc
         assert float(np.abs(got - want).max()) <= 4.0 * float(self_diff.max()) + 2e-5, (np.abs(got - want).max(), self_diff.max())
 
 
+@pytest.mark.parametrize("kw", [C3, dict(sample_rate=96000.0, lowpass_in=12500.0, lowpass_out=6500.0),
+                                dict(lowpass_in=9600.0), dict(lowpass_in=12500.0, in_degree=5, mode=0x12)],
+                         ids=["c3", "readme_96k", "L9600", "cheby_D5"])
+def test_adversarial_small_filtered_samples(orc, kw):
+    """The worst places for the complex stencil's arithmetic, searched rather than waited for: of
+    all 65,536 byte pairs per lane, the ones whose filtered value h0 x0 + h1 x1 (+ bias) comes out
+    closest to zero, combined into the 1,024 sample pairs with the smallest |z| of the design
+    (down to 1e-3, where a random stream reaches 1e-2 once in 1e10 samples) and planted at both
+    alignments among random neighbours.  The discriminator value there is error / |z| radians off;
+    the criterion's clause, pinned to the reference's own self-difference, has to hold."""
+    opt = dm.Options(buf_size=65536, **kw)
+    din = dm.design(opt, "in")
+    h = np.asarray(din["taps"], dtype=np.float64)
+    assert h.size == 2
+    v = np.arange(-128, 128, dtype=np.float64)
+    lane = h[0] * v[:, None] + h[1] * v[None, :]                     # every (x0, x1)
+    best = []
+    for bias in (0.0, float(din["bias_im"])):
+        flat = np.argsort(np.abs(lane + bias), axis=None)[:32]
+        best.append([(int(v[i // 256]), int(v[i % 256])) for i in flat])
+    pairs = [(re, im) for re in best[0] for im in best[1]]           # 1,024 sample pairs, |z| smallest first-ish
+    rng = np.random.default_rng(5)
+    n_chunks = 4
+    data = rng.integers(0, 256, n_chunks * opt.buf_size, dtype=np.uint8)
+    slots = rng.permutation(np.arange(40, n_chunks * opt.buf_size // 2 - 40, 7))[:len(pairs)]   # odd stride: both alignments
+    for k, ((r0, r1), (i0, i1)) in zip(slots, pairs):
+        data[2 * k:2 * k + 4] = ((r0 + 127) & 255, (i0 + 127) & 255, (r1 + 127) & 255, (i1 + 127) & 255)
+    with dm.Demodulator(opt) as d:
+        got = d.process_host(data)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    rep = _check(f"adversarial {kw}", got, want, opt, data)
+    print(f"adversarial {kw}: {rep}")
+
+
 def test_random_call_patterns(orc):
     """Seeded sweep over HOW a stream reaches the path rather than over its options: one stream,
     cut at random rows into several calls (each with its chunk offset and the 64 bytes that
