@@ -456,32 +456,45 @@ def test_ill_conditioned_sample_of_a_design_whose_folded_constant_is_inexact(orc
 
 
 @pytest.mark.parametrize("kw", [C3, dict(sample_rate=96000.0, lowpass_in=12500.0, lowpass_out=6500.0),
-                                dict(lowpass_in=9600.0), dict(lowpass_in=12500.0, in_degree=5, mode=0x12)],
-                         ids=["c3", "readme_96k", "L9600", "cheby_D5"])
+                                dict(lowpass_in=9600.0), dict(lowpass_in=12500.0, in_degree=5, mode=0x12),
+                                dict(lowpass_in=12500.0, in_degree=6), dict(lowpass_in=9600.0, in_degree=8, out_degree=7, sample_rate=96000.0),
+                                dict(mode=0x1C, lowpass_in=12500.0, lowpass_out=6500.0)],
+                         ids=["c3", "readme_96k", "L9600", "cheby_D5", "D6_3tap", "D8d7_96k_3tap", "q3_L"])
 def test_adversarial_small_filtered_samples(orc, kw):
     """The worst places for the complex stencil's arithmetic, searched rather than waited for: of
-    all 65,536 byte pairs per lane, the ones whose filtered value h0 x0 + h1 x1 (+ bias) comes out
-    closest to zero, combined into the 1,024 sample pairs with the smallest |z| of the design
-    (down to 1e-3, where a random stream reaches 1e-2 once in 1e10 samples) and planted at both
-    alignments among random neighbours.  The discriminator value there is error / |z| radians off;
-    the criterion's clause, pinned to the reference's own self-difference, has to hold."""
+    all byte combinations a lane's stencil can meet (256^2 with two taps, 256^3 with three), the
+    ones whose filtered value sum_j h_j x_j (+ bias) comes out closest to zero, combined into the
+    1,024 sample groups with the smallest |z| of the design (down to 1e-3, where a random stream
+    reaches 1e-2 once in 1e10 samples) and planted at both alignments among random neighbours.
+    The discriminator value there is error / |z| radians off; the criterion's clause, pinned to
+    the reference's own self-difference, has to hold."""
     opt = dm.Options(buf_size=65536, **kw)
     din = dm.design(opt, "in")
     h = np.asarray(din["taps"], dtype=np.float64)
-    assert h.size == 2
-    v = np.arange(-128, 128, dtype=np.float64)
-    lane = h[0] * v[:, None] + h[1] * v[None, :]                     # every (x0, x1)
+    T = h.size
+    assert T in (2, 3)
+    if (opt.mode >> 2) & 3 == 3:
+        v = np.arange(256, dtype=np.float64) * (2.0 / 255.0) - 1.0   # -q3: byte * 2/255 - 1
+        to_byte = lambda i: i                                        # noqa: E731
+    else:
+        v = np.arange(-128, 128, dtype=np.float64)                   # (int8)(byte - 127)
+        to_byte = lambda i: (i - 128 + 127) & 255                    # noqa: E731
+    lane = h[0] * v[:, None] + h[1] * v[None, :]
+    if T == 3:
+        lane = lane[:, :, None] + h[2] * v[None, None, :]
     best = []
     for bias in (0.0, float(din["bias_im"])):
-        flat = np.argsort(np.abs(lane + bias), axis=None)[:32]
-        best.append([(int(v[i // 256]), int(v[i % 256])) for i in flat])
-    pairs = [(re, im) for re in best[0] for im in best[1]]           # 1,024 sample pairs, |z| smallest first-ish
+        flat = np.argpartition(np.abs(lane + bias), 32, axis=None)[:32]
+        best.append([np.unravel_index(int(i), lane.shape) for i in flat])
+    groups = [(re, im) for re in best[0] for im in best[1]]          # 1,024 groups of T complex samples
     rng = np.random.default_rng(5)
     n_chunks = 4
     data = rng.integers(0, 256, n_chunks * opt.buf_size, dtype=np.uint8)
-    slots = rng.permutation(np.arange(40, n_chunks * opt.buf_size // 2 - 40, 7))[:len(pairs)]   # odd stride: both alignments
-    for k, ((r0, r1), (i0, i1)) in zip(slots, pairs):
-        data[2 * k:2 * k + 4] = ((r0 + 127) & 255, (i0 + 127) & 255, (r1 + 127) & 255, (i1 + 127) & 255)
+    slots = rng.permutation(np.arange(40, n_chunks * opt.buf_size // 2 - 40, 7))[:len(groups)]   # odd stride: both alignments
+    for k, (re, im) in zip(slots, groups):
+        for j in range(T):
+            data[2 * (k + j)] = to_byte(int(re[j]))
+            data[2 * (k + j) + 1] = to_byte(int(im[j]))
     with dm.Demodulator(opt) as d:
         got = d.process_host(data)
     want = orc.process(oracle.Flags(**opt.__dict__), data)
