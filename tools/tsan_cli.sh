@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the CLI and its backend built with ThreadSanitizer on the host side (demodulator_amd/variants/tsan, built
-# here: hipcc ... -Xarch_host -fsanitize=thread; /opt/rocm/lib/llvm/bin/clang -fsanitize=thread for backend.c and main.c), file -> file, pipe -> pipe, tiny chunks, -q1.
+# here by tools/build_tsan.sh), file -> file, pipe -> pipe, tiny chunks, -q1.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 V=demodulator_amd/variants/tsan
 D=/dev/shm/tsan.$$; mkdir -p $D
