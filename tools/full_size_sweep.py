@@ -15,7 +15,7 @@ seed = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0x5EED
 orc = oracle.restatement()
 threads = max(1, min(len(os.sched_getaffinity(0)), 64))
 L = dict(lowpass_in=12500.0, lowpass_out=6500.0)
-cases = [("-S 96000 -L 12500 -l 6500 (README)", dict(sample_rate=96000.0, **L)), ("-L 9600", dict(lowpass_in=9600.0)),
+cases = [("C2 (defaults)", {}), ("C3 / target (-L 12500 -l 6500)", L), ("-S 96000 -L 12500 -l 6500 (README)", dict(sample_rate=96000.0, **L)), ("-L 9600", dict(lowpass_in=9600.0)),
          ("-S 96000 -l 12500 (README, no -L)", dict(sample_rate=96000.0, lowpass_out=12500.0)),
          ("-m 3 -L 12500 -l 6500 (Chebyshev)", dict(mode=0x13, **L)), ("-L -D 6 -d 6 (3 taps)", dict(in_degree=6, out_degree=6, **L)),
          ("-q 3 -L", dict(mode=0x1C, **L)), ("-q 2", dict(mode=0x18)), ("-L -D 9 -d 9", dict(in_degree=9, out_degree=9, **L)),
