@@ -502,6 +502,39 @@ def test_adversarial_small_filtered_samples(orc, kw):
     print(f"adversarial {kw}: {rep}")
 
 
+def test_nothing_is_written_outside_the_result(orc):
+    """Every kernel that stores results (streaming, bounds-checked, chunk heads in their three
+    forms, the literal kernel for tiny chunks, -q1's consumer, int16 stores) writes n_bytes / 4
+    results and nothing else: guard bands of a bit pattern no result has, on both sides of the
+    result buffer, stay untouched for ragged lengths, chunk offsets and every chunk size class."""
+    import torch
+    guard = 4096
+    rng = np.random.default_rng(99)
+    cases = [(dict(), 262144), (C3, 262144), (C3, 1024), (C3, 2048), (dict(out_degree=16), 65536), (dict(lowpass_in=9000.0, in_degree=12, out_degree=9), 16384),
+             (dict(mode=0x18, lowpass_in=12500.0), 8192), (dict(mode=0x14), 4096), (dict(mode=0x14, lowpass_in=12500.0), 64), (C3, 256), (dict(), 4), (dict(mode=0x1C), 16)]
+    for kw, B in cases:
+        opt = dm.Options(buf_size=B, **kw)
+        for fmt in ("f32", "s16"):
+            for n_bytes in (3 * B + (B // 2 & ~3), 5 * B, max(4, (B // 4) & ~3), 2 * B + 4):
+                data = rng.integers(0, 256, n_bytes, dtype=np.uint8)
+                iq = torch.from_numpy(data).cuda()
+                with dm.Demodulator(opt) as d:
+                    if fmt == "s16":
+                        d.set_output_format("s16", 0.05)
+                    d.set_head_mode(int(rng.choice([-1, 0, 1, 2])))
+                    odt = torch.int16 if fmt == "s16" else torch.float32
+                    n_out = n_bytes // 4
+                    buf = torch.full((guard + n_out + guard,), -21555 if fmt == "s16" else -7.7779e33, dtype=odt, device="cuda")
+                    before = buf.clone()
+                    d.process(iq, buf[guard:guard + n_out])
+                    torch.cuda.synchronize()
+                    assert torch.equal(buf[:guard], before[:guard]) and torch.equal(buf[guard + n_out:], before[guard + n_out:]), (kw, B, fmt, n_bytes)
+                with dm.Demodulator(opt) as d:          # (a context of its own: -q1 carries its offsets from call to call)
+                    if fmt == "s16":
+                        d.set_output_format("s16", 0.05)
+                    assert torch.equal(buf[guard:guard + n_out], d.process(iq)), (kw, B, fmt, n_bytes)
+
+
 def test_random_call_patterns(orc):
     """Seeded sweep over HOW a stream reaches the path rather than over its options: one stream,
     cut at random rows into several calls (each with its chunk offset and the 64 bytes that
