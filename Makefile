@@ -45,7 +45,7 @@ oracle:
 	$(MAKE) -C oracle
 
 # instruction-rate and streaming-pattern microbenchmarks behind DESIGN.md section 4.1 (run on the GPU box)
-microbench: tools/microbench/valu_rate tools/microbench/stream_copy tools/microbench/chain_latency
+microbench: tools/microbench/valu_rate tools/microbench/stream_copy tools/microbench/chain_latency tools/microbench/policy_sweep
 tools/microbench/%: tools/microbench/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 

@@ -555,10 +555,38 @@ __device__ __forceinline__ uint4 load_row16(const uint8_t *row_base, uint32_t la
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Cache policy of the result stores.  hipcc's __builtin_nontemporal_store gives "nt"; the bare
+// copy with this kernel's pattern (tools/microbench/policy_sweep.hip: 4 rows per wavefront
+// requested up front, "nt" loads) runs at 0.801 of peak with "nt" stores and at 0.814 with
+// "sc1 nt" (0.810 "sc1", 0.747 none).  The kernel follows where memory alone binds it: without a
+// complex stage (BASELINE config 2) 0.797 -> 0.809 and 0.805 -> 0.814 on two boxes, three
+// interleaved rounds each; with one (config 3, the target) +0.3 % on one box, -0.4 % on the
+// other -- there the VALU side co-limits and the policy stays "nt" (profiles/r2_ab_workgroup.txt).
+// There is no builtin for sc1: that store is spelled out, with the wait states a VALU write to
+// the data registers of a wide store needs behind it (hipcc cannot see into the statement).
+// DEMOD_STORE_POLICY_ID (experiments): 0 = by build as above, 1 = " nt" spelled out everywhere
+// (control), 2 = " sc1 nt" everywhere, 3 = " sc0 sc1 nt", 4 = " sc1", 5 = the builtin everywhere.
+#ifndef DEMOD_STORE_POLICY_ID
+#define DEMOD_STORE_POLICY_ID 0
+#endif
+#if DEMOD_STORE_POLICY_ID == 1
+#define DEMOD_STORE_POLICY " nt"
+#elif DEMOD_STORE_POLICY_ID == 3
+#define DEMOD_STORE_POLICY " sc0 sc1 nt"
+#elif DEMOD_STORE_POLICY_ID == 4
+#define DEMOD_STORE_POLICY " sc1"
+#else
+#define DEMOD_STORE_POLICY " sc1 nt"
+#endif
+// WIDE: this build's stores take the spelled-out policy
+template <bool WIDE>
 __device__ __forceinline__ void store_out16(float *dst, const float (&y)[4]) {
     f32x4 v;
     v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+    if constexpr (DEMOD_STORE_POLICY_ID != 5 && (WIDE || DEMOD_STORE_POLICY_ID != 0))
+        asm volatile("global_store_dwordx4 %0, %1, off" DEMOD_STORE_POLICY "\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+    else
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
 }
 
 // int16 output (DEMOD_OUT_S16): one signed-normalised conversion per pair,
@@ -578,10 +606,10 @@ __device__ __forceinline__ void store_out8_s16(void *dst, const float (&y)[4], f
     __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(dst));
 }
 // Four results of one lane to element `index` of the output, in the output's format.
-template <bool S16>
+template <bool S16, bool WIDE = false>
 __device__ __forceinline__ void store_quad(void *dst, const float (&y)[4], float scale) {
     if constexpr (S16) store_out8_s16(dst, y, scale);
-    else store_out16(static_cast<float *>(dst), y);
+    else store_out16<WIDE>(static_cast<float *>(dst), y);
 }
 template <bool S16>
 __device__ __forceinline__ char *out_address(void *base, uint64_t index) {
@@ -923,7 +951,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
                 process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
                 // (the first lanes of a chunk's first row hold interior-formula values for
                 // outputs that are not interior: chunk_head / demod_heads overwrites them)
-                store_quad<S16>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane), y, a.out_scale);
+                store_quad<S16, TIN == 0>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane), y, a.out_scale);
             }
             if constexpr (!FULL) {
                 // the stand-in loads of the missing rows land in registers hipcc believes free

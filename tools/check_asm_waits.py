@@ -28,7 +28,7 @@ SRC = os.path.join(ROOT, "demodulator_amd", "csrc", "kernels.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm",
          "-amdgpu-sched-strategy=max-ilp", "-Wno-pass-failed", f"-I{ROOT}/include",
-         f"-I{ROOT}/demodulator_amd/csrc", "-S", "--cuda-device-only"]
+         f"-I{ROOT}/demodulator_amd/csrc", "-S", "--cuda-device-only"] + os.environ.get("DEMOD_CHECK_FLAGS", "").split()
 
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
