@@ -20,9 +20,15 @@ template <int SP> __device__ __forceinline__ void st(void *p, const u32x4 &v) {
 #undef X
 }
 
-template <int LP, int SP, int ROWS> __global__ __launch_bounds__(256, 2) void k(const uint8_t *in, uint8_t *out, uint32_t n_seg) {
+// MAP: which segments a workgroup (= an XCD, round-robin) takes: 0 as demod_rows (XCD x streams segments x, x+8, x+16, x+24 of a
+// group of 32), 1 four consecutive ones, 2 two pairs (2x, 2x+1, 2x+16, 2x+17), 3 x, x+8, ... of a group of 64 over 16 workgroups
+template <int LP, int SP, int ROWS, int MAP = 0> __global__ __launch_bounds__(256, 2) void k(const uint8_t *in, uint8_t *out, uint32_t n_seg) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t seg = (blockIdx.x / 8u) * 32u + wave * 8u + blockIdx.x % 8u;   // XCD x streams segments x, x+8, ... of a group
+    uint32_t seg;
+    if constexpr (MAP == 0) seg = (blockIdx.x / 8u) * 32u + wave * 8u + blockIdx.x % 8u;
+    else if constexpr (MAP == 1) seg = blockIdx.x * 4u + wave;
+    else if constexpr (MAP == 2) seg = (blockIdx.x / 8u) * 32u + (wave >> 1) * 16u + (blockIdx.x % 8u) * 2u + (wave & 1u);
+    else seg = (blockIdx.x / 16u) * 64u + (wave * 2u + (blockIdx.x % 16u) / 8u) * 8u + blockIdx.x % 8u;
     if (seg >= n_seg) return;
     const size_t base = (size_t) seg * ROWS * 1024 + 16u * lane;
     u32x4 q[ROWS];
@@ -40,13 +46,13 @@ static const char *names[] = {"(none)", "nt", "sc0", "sc1", "sc0 sc1", "sc0 nt",
 static uint8_t *a, *b;
 static const size_t bytes = 1ull << 32;
 
-template <int LP, int SP, int ROWS> float run() {
+template <int LP, int SP, int ROWS, int MAP = 0> float run() {
     const uint32_t n_seg = (uint32_t) (bytes / 1024 / ROWS);
     const uint32_t blocks = (n_seg + 3) / 4;
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k<LP, SP, ROWS>), dim3(blocks), dim3(256), 0, 0, a, b, n_seg);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k<LP, SP, ROWS, MAP>), dim3(blocks), dim3(256), 0, 0, a, b, n_seg);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((k<LP, SP, ROWS>), dim3(blocks), dim3(256), 0, 0, a, b, n_seg);
+    for (int i = 0; i < 6; ++i) hipLaunchKernelGGL((k<LP, SP, ROWS, MAP>), dim3(blocks), dim3(256), 0, 0, a, b, n_seg);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms / 6;
@@ -65,5 +71,11 @@ int main() {
     row<0, 4>(); row<1, 4>(); row<2, 4>(); row<3, 4>(); row<4, 4>(); row<5, 4>(); row<6, 4>(); row<7, 4>();
     row<0, 1>(); row<1, 1>(); row<4, 1>(); row<7, 1>();
     row<1, 2>(); row<1, 8>();
+    printf("segment-to-workgroup maps (loads nt; stores nt / sc1 nt), 4 rows per wavefront: as demod_rows %.3f / %.3f, consecutive %.3f / %.3f, pairs %.3f / %.3f, group of 64 %.3f / %.3f\n",
+           2.0 * bytes / (run<1, 1, 4, 0>() * 1e-3) / 8e12, 2.0 * bytes / (run<1, 6, 4, 0>() * 1e-3) / 8e12, 2.0 * bytes / (run<1, 1, 4, 1>() * 1e-3) / 8e12,
+           2.0 * bytes / (run<1, 6, 4, 1>() * 1e-3) / 8e12, 2.0 * bytes / (run<1, 1, 4, 2>() * 1e-3) / 8e12, 2.0 * bytes / (run<1, 6, 4, 2>() * 1e-3) / 8e12,
+           2.0 * bytes / (run<1, 1, 4, 3>() * 1e-3) / 8e12, 2.0 * bytes / (run<1, 6, 4, 3>() * 1e-3) / 8e12);
+    printf("the same with 1 / 2 / 8 rows per wavefront, consecutive: %.3f / %.3f / %.3f (sc1 nt stores)\n", 2.0 * bytes / (run<1, 6, 1, 1>() * 1e-3) / 8e12,
+           2.0 * bytes / (run<1, 6, 2, 1>() * 1e-3) / 8e12, 2.0 * bytes / (run<1, 6, 8, 1>() * 1e-3) / 8e12);
     return 0;
 }
