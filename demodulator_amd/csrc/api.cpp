@@ -716,6 +716,14 @@ double demod_design_magnitude_bound(const demod_params *p) {
     return plan.magnitude_bound;
 }
 
+int demod_design_unpack_folded(const demod_params *p) {
+    if (!p) return create_fail(DEMOD_E_INVAL, "null argument");
+    Plan plan;
+    std::string err;
+    if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
+    return plan.conditioning == kShiftOrigin && plan.stencil_in.taps > 0 ? 1 : 0;
+}
+
 int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed,
                      void *stream) {
     if (!ctx || !d_dst || (first_byte & 15) || (n_bytes & 15) || ((uintptr_t) d_dst & 15)) {

@@ -70,7 +70,8 @@ def design(options: Options, which: str = "out") -> dict:
     if n < 0:
         raise DemodError(f"demod_design_query failed ({n}): {lib.demod_last_error(None).decode()}")
     return {"sos": rows[:n].copy(), "taps": taps[:n_taps.value].copy(), "bias_im": float(bias.value),
-            "head_outputs": int(head.value), "magnitude_bound": float(lib.demod_design_magnitude_bound(C.byref(p)))}
+            "head_outputs": int(head.value), "magnitude_bound": float(lib.demod_design_magnitude_bound(C.byref(p))),
+            "unpack_folded": bool(lib.demod_design_unpack_folded(C.byref(p)) == 1)}
 
 
 class Demodulator:

@@ -263,6 +263,14 @@ int demod_design_query(const demod_params *p, int which, float *rows6, int max_r
  * a negative error code (as a double) with the text in demod_last_error(NULL). */
 double demod_design_magnitude_bound(const demod_params *p);
 
+/* Which unpack arithmetic the streaming kernel uses for an option set with the default
+ * shiftOrigin conditioning and a complex stage: 1 = the unpack hands the stencil 128 + sample
+ * and the stencil's constant absorbs the -128 (one operation per sample less; chosen when that
+ * constant, -128 * sum of the taps, is exactly a float -- the BASELINE designs), 0 = 128 is
+ * subtracted from the samples (every other case).  Negative: error code, text in
+ * demod_last_error(NULL). */
+int demod_design_unpack_folded(const demod_params *p);
+
 /* Seamless mode (not reference behaviour; off by default): the whole stream is
  * filtered as ONE chunk, so the look-ahead stencils run across what would be
  * chunk boundaries instead of restarting with zero padding every buf_size bytes
