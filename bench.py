@@ -257,6 +257,13 @@ def main() -> int:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)   # before torch is imported: the parent never touches the GPU
 
+    # stdout carries ONE line, the JSON: whatever libraries print there on the way (gloo announces its
+    # connections on std::cout, "[Gloo] Rank 0 is connected to ...") goes to stderr instead -- file
+    # descriptor 1 points at stderr from here on, the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -427,7 +434,7 @@ def main() -> int:
                 return host
 
             line["cpu_baseline"] = cpu_baseline(min(29, wl["log2_samples"]), {**wl["flags"]}, wl["seed"], fetch)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if world > 1:
         dist.barrier()

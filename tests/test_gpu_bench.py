@@ -19,7 +19,9 @@ def _bench(args, **env):
     e.pop("WORLD_SIZE", None)
     e.pop("RANK", None)
     r = subprocess.run([sys.executable, BENCH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=e)
-    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    lines = r.stdout.decode().splitlines()
+    # the contract is ONE line on stdout (gloo's "[Gloo] Rank 0 is connected to ..." chatter once landed there)
+    assert len(lines) <= 1, lines
     return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr.decode()[-2000:]
 
 
@@ -70,7 +72,7 @@ def test_two_ranks_under_torch_distributed_run_as_the_driver_launches_them():
                         "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2",
                         "--workload", "c3", "--steps", "3", "--warmup", "1"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=e)
-    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, r.stderr.decode()[-2000:]
+    lines = r.stdout.decode().splitlines()
+    assert r.returncode == 0 and len(lines) == 1, (lines, r.stderr.decode()[-2000:])   # one line on stdout, nothing else
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["halo_exchange"].startswith("gloo send/recv") and line["value"] > 0
