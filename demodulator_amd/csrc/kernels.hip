@@ -656,7 +656,12 @@ __device__ __forceinline__ float section_update(const float (&row)[6], float cur
     return t - (row[3] + row[4] * x0 + row[5] * x1);
 }
 
-template <int COND, bool S16, int MAXSEC = kFusedSections, class LAUNCH = RowLaunch>
+// PRE (demod_heads_wave only): -q2 in front of -L.  highpassDc runs first, the same recurrence with
+// its own two sections from a buffer of its own; the -L stage then reads ITS cells instead of the
+// samples, and finds highpassDc's overflow cells -- three constants of the design, its inputs
+// behind its buffer being zeros -- where its own output starts (src/matrix.c:155-156, :260-264:
+// filterRet + bufSize is both).
+template <int COND, bool S16, int MAXSEC = kFusedSections, class LAUNCH = RowLaunch, bool PRE = false>
 __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane, uint32_t n_out) {
     // the segment's own stores (among them the interior-formula values of this row's first
     // lanes, which are overwritten below) are complete before anything here is stored
@@ -670,18 +675,66 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
     const float x2r = unpack_byte<COND>((uint8_t) w1, a.scale), x2i = unpack_byte<COND>((uint8_t) (w1 >> 8), a.scale);
     float Ar = x0r, Ai = x0i, Br = x1r, Bi = x1i;  // what the discriminator reads: samples, or the complex stage's cells 2n, 2n+1
     float y0 = 0.f;                                // what the output stage finds in its cell n
+    // what the complex stage reads (cells 2n, 2n+1, 2n+2) and what its own cells 2n, 2n+1 hold before it runs
+    float u0r = x0r, u0i = x0i, u1r = x1r, u1i = x1i, u2r = x2r, u2i = x2i;
+    float sAr = 0.f, sAi = 0.f, sBr = 0.f, sBi = 0.f;
+    if constexpr (PRE) {
+        if (a.sec_pre > 0) {
+            const int Sp = a.sec_pre;
+            float cAr = 0.f, cAi = 0.f, cBr = 0.f, cBi = 0.f, pAr = 0.f, pAi = 0.f, pBr = 0.f, pBi = 0.f;
+            const int cellA = 2 * (int) lane;
+#pragma unroll
+            for (int m = 1; m >= 0; --m) {
+                if (m < Sp) {
+                    const float nBr = from_next_lane(pAr, 0.f), nBi = from_next_lane(pAi, 0.f);
+                    const float vAr = section_update<true>(a.sos_pre[m], cAr, pBr, x0r, x1r);
+                    const float vAi = section_update<false>(a.sos_pre[m], cAi, pBi, x0i, x1i);
+                    const float vBr = section_update<true>(a.sos_pre[m], cBr, nBr, x1r, x2r);
+                    const float vBi = section_update<false>(a.sos_pre[m], cBi, nBi, x1i, x2i);
+                    const bool exA = cellA - Sp - m >= 0, exB = cellA + 1 - Sp - m >= 0;
+                    pAr = cAr; pAi = cAi; pBr = cBr; pBi = cBi;
+                    cAr = exA ? vAr : cAr; cAi = exA ? vAi : cAi;
+                    cBr = exB ? vBr : cBr; cBi = exB ? vBi : cBi;
+                }
+            }
+            u0r = cAr; u0i = cAi; u1r = cBr; u1i = cBi;
+            u2r = from_next_lane(cAr, 0.f); u2i = from_next_lane(cAi, 0.f);
+            // highpassDc's overflow cells K + t, t < 2 Sp - 1 (the same for every chunk: inputs 0.0f)
+            float hr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int t = u + 1 - Sp + m;
+                    if (u < 2 * Sp - 1 && m < Sp && t >= 0) {
+                        const float b0 = a.sos_pre[m][0], b1 = a.sos_pre[m][1];
+                        const float a0 = a.sos_pre[m][3], a1 = a.sos_pre[m][4], a2 = a.sos_pre[m][5];
+                        float v = b0 * hr[t] + b1 * hr[t + 1] + 1.0f;
+                        hr[t] = v - (a0 + a1 * 0.f + a2 * 0.f);
+                        v = b0 * hi[t] + b1 * hi[t + 1];
+                        hi[t] = v - (a0 + a1 * 0.f + a2 * 0.f);
+                    }
+                }
+            }
+            const int nh = 2 * Sp - 1;  // cell 2n of the -L stage's output is overflow cell 2n, cell 2n+1 is 2n+1
+            sAr = lane == 0u ? hr[0] : (lane == 1u && nh > 2 ? hr[2] : 0.f);
+            sAi = lane == 0u ? hi[0] : (lane == 1u && nh > 2 ? hi[2] : 0.f);
+            sBr = lane == 0u && nh > 1 ? hr[1] : 0.f;
+            sBi = lane == 0u && nh > 1 ? hi[1] : 0.f;
+        }
+    }
     if (Si > 0) {
         // complex stage, cells A = 2n and B = 2n + 1; c* = P(cell, m+1), p* = P(cell, m+2)
-        float cAr = 0.f, cAi = 0.f, cBr = 0.f, cBi = 0.f, pAr = 0.f, pAi = 0.f, pBr = 0.f, pBi = 0.f;
+        float cAr = sAr, cAi = sAi, cBr = sBr, cBi = sBi, pAr = sAr, pAi = sAi, pBr = sBr, pBi = sBi;
         const int cellA = 2 * (int) lane;
 #pragma unroll
         for (int m = MAXSEC - 1; m >= 0; --m) {
             if (m < Si) {
                 const float nBr = from_next_lane(pAr, 0.f), nBi = from_next_lane(pAi, 0.f);  // cell 2n + 2 lives in the next lane
-                const float vAr = section_update<true>(a.sos_in[m], cAr, pBr, x0r, x1r);
-                const float vAi = section_update<false>(a.sos_in[m], cAi, pBi, x0i, x1i);
-                const float vBr = section_update<true>(a.sos_in[m], cBr, nBr, x1r, x2r);
-                const float vBi = section_update<false>(a.sos_in[m], cBi, nBi, x1i, x2i);
+                const float vAr = section_update<true>(a.sos_in[m], cAr, pBr, u0r, u1r);
+                const float vAi = section_update<false>(a.sos_in[m], cAi, pBi, u0i, u1i);
+                const float vBr = section_update<true>(a.sos_in[m], cBr, nBr, u1r, u2r);
+                const float vBi = section_update<false>(a.sos_in[m], cBi, nBi, u1i, u2i);
                 const bool exA = cellA - Si - m >= 0, exB = cellA + 1 - Si - m >= 0;
                 pAr = cAr; pAi = cAi; pBr = cBr; pBi = cBi;
                 cAr = exA ? vAr : cAr; cAi = exA ? vAi : cAi;
@@ -1174,17 +1227,17 @@ __global__ __launch_bounds__(64) void demod_heads(const HeadLaunch a) {
 // few thousand chunks per dispatch that is one long latency chain (0.15 ms per 2^30 bytes of
 // default chunks at -L -D 9 -d 9).  chunk_head's lane-parallel replay has no such chain; here it
 // runs with room for kMaxSections sections, one wavefront per head.  Same operations on the same
-// values as the thread-per-chunk kernel (tests compare the two bit for bit).  Not for -q1 and
-// not with highpassDc in front of -L (chunk_head has neither); the chunk must hold the window
-// the 64 lanes read (264 bytes: every chunk of a whole row does).
+// values as the thread-per-chunk kernel (tests compare the two bit for bit), highpassDc in front
+// of -L included (PRE).  Not for -q1 (chunk_head has no offsets table); the chunk must hold the
+// window the 64 lanes read (264 bytes: every chunk of a whole row does).
 constexpr int kHeadWaves = 4;
 template <int COND, bool S16>
 __global__ __launch_bounds__(64 * kHeadWaves) void demod_heads_wave(const HeadLaunch a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t head = blockIdx.x * (uint32_t) kHeadWaves + (threadIdx.x >> 6);
     if (head >= a.n_heads) return;
-    chunk_head<COND, S16, kWaveHeadSections, HeadLaunch>(a, a.in + (uint64_t) head * a.chunk_bytes,
-                                                         (uint64_t) head * (a.chunk_bytes >> 2), lane, a.head_outputs);
+    chunk_head<COND, S16, kWaveHeadSections, HeadLaunch, true>(a, a.in + (uint64_t) head * a.chunk_bytes,
+                                                               (uint64_t) head * (a.chunk_bytes >> 2), lane, a.head_outputs);
 }
 
 // ---------------------------------------------------------------------------
@@ -1659,9 +1712,9 @@ void launch_heads_c(const HeadLaunch &a, hipStream_t s) {
 #undef DEMOD_HEADS_CASE
     // any other design: one wavefront per head where chunk_head covers the case (see
     // demod_heads_wave), the thread-per-chunk replay with its cells in scratch for the rest --
-    // -q1, highpassDc in front of -L, a last chunk shorter than the lanes' window
+    // -q1, a last chunk shorter than the lanes' window
     if constexpr (COND != kCorrectIq) {
-        if (!a.thread_per_head && a.sec_pre == 0 && a.head_outputs <= 64u && a.chunk_bytes >= kRowBytes) {
+        if (!a.thread_per_head && a.sec_pre <= 2 && a.head_outputs <= 64u && a.chunk_bytes >= kRowBytes) {
             const uint32_t by_wave = a.last_chunk_bytes >= kRowBytes ? a.n_heads : a.n_heads - 1u;
             if (by_wave) {
                 HeadLaunch w = a;

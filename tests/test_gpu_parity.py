@@ -877,7 +877,8 @@ def test_correct_iq_q1(orc, kw, n_bytes):
     dict(out_degree=1), dict(lowpass_in=12500.0, in_degree=1, out_degree=8),
     dict(lowpass_in=12500.0, lowpass_out=6500.0, in_degree=9, out_degree=9), dict(lowpass_in=9000.0, in_degree=16, out_degree=12),
     dict(out_degree=16), dict(mode=0x1C, lowpass_in=12500.0, in_degree=11, out_degree=3), dict(mode=0x13, lowpass_in=9600.0, in_degree=10, out_degree=14),
-], ids=["c2", "c3", "D8d7", "cheby_D5d2", "q2", "q3_L", "d1", "D1d8", "D9d9", "D16d12", "d16", "q3_D11d3", "cheby_D10d14"])
+    dict(mode=0x18, lowpass_in=12500.0, lowpass_out=6500.0), dict(mode=0x1A, lowpass_in=9600.0, in_degree=7, out_degree=9, sample_rate=96000.0),
+], ids=["c2", "c3", "D8d7", "cheby_D5d2", "q2", "q3_L", "d1", "D1d8", "D9d9", "D16d12", "d16", "q3_D11d3", "cheby_D10d14", "q2_L", "q2_cheby_D7d9"])
 def test_chunk_heads_in_the_streaming_kernel_equal_the_head_kernel(kw):
     """The first outputs of every chunk are replayed literally either by the wavefront that owns
     the chunk's first row (chunk_head: one output per lane), by a wavefront of demod_heads_wave
