@@ -15,12 +15,11 @@
 //              reference's sectioned recurrences for the first few outputs of
 //              the chunk (partial sections, overflow pollution; SURVEY.md
 //              Appendix A.4), one output per lane (chunk_head).
-// demod_heads  the same replay, one thread per chunk, for what chunk_head does
-//              not cover: -q2 in front of -L, -q1, chunks below 256 KiB (where a
-//              kernel of its own is cheaper) and the chunks of a bounds-checked
-//              (ragged) launch.
-// demod_heads_wave  chunk_head with room for 8 sections per stage, one wavefront
-//              per chunk: designs of degree 9-16.
+// demod_heads  the same replay, one thread per chunk: -q1, the default designs
+//              with chunks below 256 KiB (where a kernel of its own is cheaper)
+//              and in a bounds-checked (ragged) launch.
+// demod_heads_wave  chunk_head with room for 8 sections per stage and for -q2 in
+//              front of -L, one wavefront per chunk: designs of degree 9-16.
 // demod_tiny   literal whole-chunk path for chunks shorter than one row.
 // correct_iq_offsets   -q1: the running DC offsets of correctIq, replayed piece by piece
 //              after a run-in, into a table the other kernels subtract from the bytes.
