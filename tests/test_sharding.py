@@ -95,7 +95,7 @@ def _worker(rank, world, port, total, B, phase, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,phase", [(2, 0), (2, 3072), (3, 1024)])
+@pytest.mark.parametrize("world,phase", [(2, 0), (2, 3072), (3, 1024), (8, 5120)])
 def test_halo_exchange_over_gloo(world, phase):
     B, seed = 16384, 0xD3300D04
     total = 5 * B + 7 * 1024
