@@ -250,8 +250,9 @@ def main() -> int:
                     help="untimed device spin-up before the warm-up steps (set-up, see run_workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
-    ap.add_argument("--probe-timeout", type=float, default=120.0,
-                    help="seconds the point-to-point health check may take before it is killed")
+    ap.add_argument("--probe-timeout", type=float, default=240.0,
+                    help="seconds the point-to-point health check may take before it is killed (on a fresh box the "
+                         "probe's processes page in torch and the 570 MB librccl before they start)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
