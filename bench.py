@@ -79,6 +79,10 @@ WORKLOADS = {
     # fused into the kernel's store (demod_set_output_format): 2 B read + 1 B written per sample
     "c3_s16": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, out="s16",
                    desc="C3 with the fused int16 output: 2^30 samples, -L 12500 -l 6500, 3 B of HBM traffic per sample"),
+    # not the default arithmetic: the unpack's -128 folded into the complex stencil's constant (demod_set_unpack_fold;
+    # faster, but outside the parity criterion at samples that filter to next to nothing: DESIGN.md section 5)
+    "c3_fold": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, fold=True,
+                    desc="C3 with the optional folded unpack (not the default arithmetic): 2^30 samples, -L 12500 -l 6500"),
 }
 PHASE_BYTES = 96 * 1024  # unaligned cut: shards start this far into a chunk
 
@@ -126,6 +130,8 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     d = dm.Demodulator(opt, device=dev.index)
     if seg_rows:
         d.set_segment_rows(seg_rows)
+    if wl.get("fold"):
+        d.set_unpack_fold(True)
     d.enable_timing(True)
 
     from demodulator_amd.sharding import exchange_halo, plan_shards
@@ -407,7 +413,7 @@ def main() -> int:
 
         if world == 1 and not args.no_extra:
             also = {}
-            for name in ("c3", "c2", "c3_s16"):
+            for name in ("c3", "c2", "c3_s16", "c3_fold"):
                 if name == args.workload:
                     continue
                 bps = 3 if WORKLOADS[name].get("out") == "s16" else ALGO_BYTES_PER_SAMPLE

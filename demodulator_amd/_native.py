@@ -27,7 +27,7 @@ EXPORTS = (
     "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_output_format",
     "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
     "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
-    "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_design_unpack_folded", "demod_set_head_mode",
+    "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_design_unpack_folded", "demod_set_unpack_fold", "demod_set_head_mode",
     "demod_stream_depth", "demod_ring_slots_for", "demod_ring_create", "demod_ring_destroy", "demod_ring_input",
     "demod_ring_commit", "demod_ring_collect", "demod_ring_release",
     "demod_plan_shards", "demod_plan_channels", "demod_multi_create", "demod_multi_destroy", "demod_multi_devices",
@@ -142,6 +142,7 @@ def load() -> C.CDLL:
         "demod_multi_last_error": (C.c_char_p, [vp]),
         "demod_design_magnitude_bound": (C.c_double, [C.POINTER(Params)]),
         "demod_design_unpack_folded": (C.c_int, [C.POINTER(Params)]),
+        "demod_set_unpack_fold": (C.c_int, [C.c_void_p, C.c_int]),
     }
     experiment = bool(os.environ.get("DEMOD_HIP_LIBRARY"))
     for name in EXPORTS:

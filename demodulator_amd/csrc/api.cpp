@@ -100,6 +100,7 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
         return create_fail(DEMOD_E_INVAL, "device index out of range");
     }
     ctx->device = device;
+    if (const char *f = getenv("DEMOD_FOLD_UNPACK")) ctx->fold_unpack = f[0] == '1';
     if ((e = hipSetDevice(device)) != hipSuccess) {
         std::string msg = std::string("HIP setup failed: ") + hipGetErrorString(e);
         demod_destroy(ctx);
@@ -159,6 +160,12 @@ int demod_set_seamless(demod_ctx *ctx, int on) {
     if (!ctx) return DEMOD_E_INVAL;
     ctx->seamless = on != 0;
     return DEMOD_OK;
+}
+
+int demod_set_unpack_fold(demod_ctx *ctx, int on) {
+    if (!ctx) return DEMOD_E_INVAL;
+    ctx->fold_unpack = on != 0;
+    return ctx->fold_unpack && !ctx->plan.fold_exact ? 1 : DEMOD_OK;   // 1: asked for, not available for this design
 }
 
 int demod_set_head_mode(demod_ctx *ctx, int mode) {
@@ -226,6 +233,11 @@ double demod_kernel_ms(demod_ctx *ctx, int *launches) {
 // chunks and above (one kernel per dispatch), the separate kernel ahead below that (128 KiB:
 // box-dependent, 64 KiB: 0.743 against 0.731 of peak, 16 KiB: 0.730 against 0.672, 1 KiB:
 // 0.37 against 0.27).
+// which unpack the streaming kernel's builds use: the plan's, or the folded form where it was asked for and is exact
+static int rows_conditioning(const demod_ctx *ctx) {
+    return ctx->fold_unpack && ctx->plan.fold_exact ? (int) kShiftOrigin : ctx->plan.conditioning;
+}
+
 static bool heads_are_fused(const demod_ctx *ctx) {
     const Plan &pl = ctx->plan;
     if (pl.conditioning == kCorrectIq) return false;  // -q1 runs in the bounds-checked build
@@ -541,7 +553,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
                 a.phase_rows = (uint32_t) (((uint64_t) phase + p0) & ((1ull << rpc_log2) - 1));
                 a.ragged_bytes = 0;
                 if (ragged || p1 < split) a.halo = nullptr;  // only the buffer's last rows can need the shard halo
-                if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, pl.conditioning, stream)) {
+                if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, rows_conditioning(ctx), stream)) {
                     ctx->fail(DEMOD_E_HIP, "demod_rows launch", hipGetLastError());
                     return DEMOD_E_HIP;
                 }
@@ -558,7 +570,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             a.phase_rows = (uint32_t) (((offset + (uint64_t) split * kRowBytes) % B) / kRowBytes);
             a.ragged_bytes = ragged;
             a.halo = nullptr;
-            if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, pl.conditioning, stream)) {
+            if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, rows_conditioning(ctx), stream)) {
                 ctx->fail(DEMOD_E_HIP, "demod_rows (ragged) launch", hipGetLastError());
                 return DEMOD_E_HIP;
             }
@@ -721,7 +733,7 @@ int demod_design_unpack_folded(const demod_params *p) {
     Plan plan;
     std::string err;
     if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
-    return plan.conditioning == kShiftOrigin && plan.stencil_in.taps > 0 ? 1 : 0;
+    return plan.fold_exact ? 1 : 0;
 }
 
 int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed,

@@ -21,6 +21,7 @@ struct demod_ctx {
     std::string err;
 
     bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
+    bool fold_unpack = false;  // demod_set_unpack_fold / DEMOD_FOLD_UNPACK=1: the folded unpack where Plan::fold_exact allows it
     int head_mode = -1;     // demod_set_head_mode: -1 automatic, 0 demod_heads kernel, 1 inside the streaming kernel
     uint32_t seg_rows = 0;  // 0 = automatic
     uint32_t piece_rows = 0;           // rows per demod_rows dispatch (set at creation)

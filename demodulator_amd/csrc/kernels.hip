@@ -401,10 +401,22 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
     constexpr int ND = 4 + TOUT - 1;
     float xr[NX], xi[NX];
     constexpr bool FOLD = fold_unpack<TIN, COND, RAGGED>();
-    unpack_dword<COND, FOLD>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
-    unpack_dword<COND, FOLD>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
-    unpack_dword<COND, FOLD>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
-    unpack_dword<COND, FOLD>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+    // the plain shiftOrigin unpack of the streaming builds takes its 128 off (re, im) pairs: eight
+    // v_pk_add_f32 instead of sixteen subtractions (the same values)
+    constexpr bool PAIRS = !RAGGED && !FOLD && (COND == kShiftOrigin || COND == kShiftOriginPlain);
+    unpack_dword<COND, FOLD || PAIRS>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+    unpack_dword<COND, FOLD || PAIRS>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+    unpack_dword<COND, FOLD || PAIRS>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+    unpack_dword<COND, FOLD || PAIRS>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+    if constexpr (PAIRS) {
+        const float k128 = opaque_128();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const pf2 p = pf2{xr[k], xi[k]} - pf2{k128, k128};
+            xr[k] = p.x;
+            xi[k] = p.y;
+        }
+    }
     if constexpr (COND == kCorrectIq) {
         // Sample k was corrected in iteration min(k, K-1-k) (q1_offset): a lane's 8 samples lie
         // on one side of the chunk's middle whenever K is a multiple of 16, and their 8 offset
@@ -459,8 +471,11 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
                 for (int j = 1; j < TIN; ++j) acc = fma2(pf2{a.hin[j], a.hin[j]}, pf2{xr[k + j], xi[k + j]}, acc);
                 z[k] = acc;
             } else {
-                // the real lane starts with a product, the imaginary lane with the bias: not a pair
-                z[k] = pf2{stencil0<TIN>(a.hin, &xr[k]), stencil<TIN>(a.hin, &xi[k], a.bias_im)};
+                // (the real lane starts from +0.0f where the imaginary lane starts from its bias: a pair)
+                pf2 acc = fma2(pf2{a.hin[0], a.hin[0]}, pf2{xr[k], xi[k]}, pf2{0.f, a.bias_im});
+#pragma unroll
+                for (int j = 1; j < TIN; ++j) acc = fma2(pf2{a.hin[j], a.hin[j]}, pf2{xr[k + j], xi[k + j]}, acc);
+                z[k] = acc;
             }
         }
         pf2 arg[4];
@@ -476,7 +491,7 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
                 zr[k] = stencil<TIN>(a.hin, &xr[k], a.fold_re);
                 zi[k] = stencil<TIN>(a.hin, &xi[k], a.fold_im);
             } else {
-                zr[k] = stencil0<TIN>(a.hin, &xr[k]);
+                zr[k] = stencil<TIN>(a.hin, &xr[k], 0.f);   // from +0.0f, as the streaming build's pair does
                 zi[k] = stencil<TIN>(a.hin, &xi[k], a.bias_im);
             }
         }
@@ -524,9 +539,9 @@ __device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunc
                     br = stencil<TIN>(a.hin, &xr[2 * j + 1], a.fold_re);
                     bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.fold_im);
                 } else {
-                    ar = stencil0<TIN>(a.hin, &xr[2 * j]);
+                    ar = stencil<TIN>(a.hin, &xr[2 * j], 0.f);   // (from +0.0f, as process_row's pairs)
                     ai = stencil<TIN>(a.hin, &xi[2 * j], a.bias_im);
-                    br = stencil0<TIN>(a.hin, &xr[2 * j + 1]);
+                    br = stencil<TIN>(a.hin, &xr[2 * j + 1], 0.f);
                     bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.bias_im);
                 }
                 d = discriminate(ar, ai, br, bi);

@@ -307,18 +307,22 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
         err = "stencil longer than supported";
         return false;
     }
-    // The streaming kernel's shiftOrigin build hands the complex stencil 128 + sample and folds the
-    // -128 into the stencil's constant, -128 * sum(h) (one operation per sample less).  That constant
-    // is a float: where it is not exactly -128 * sum(h) -- L = 9600 Hz at 125 kS/s: off by half an ulp,
-    // 7.6e-6 -- every filtered sample carries the difference, and a filtered sample that comes out
-    // next to zero (|z| = 0.01 happens once in 1e10) turns by more than the reference's own builds
-    // differ there.  Such designs take the build that subtracts 128 from the samples instead
-    // (kShiftOriginPlain: 3.6 % slower); the BASELINE designs' constants are exact.
+    // The streaming kernel has two forms of the shiftOrigin unpack in front of a complex stencil: the
+    // plain one subtracts 128 from the samples; the folded one hands the stencil 128 + sample and lets
+    // the stencil's constant absorb -128 * sum(h) (one operation per sample less, +3.6 % throughput).
+    // The folded form rounds intermediates twice as large, and its constant is a float: where that is
+    // not exactly -128 * sum(h) (L = 9600 Hz at 125 kS/s: half an ulp, 7.6e-6, in every filtered
+    // sample) a sample that filters to |z| = 0.01 was 1.7e-3 off where the reference's own builds
+    // differ by 1e-4; and with an exact constant, sample groups SEARCHED for the smallest |z| of a
+    // design left the parity criterion in half of 82 random designs, the plain form in none of 168
+    // (tools/adversarial_sweep.py).  The plain form is the default; the folded one is an option
+    // (demod_set_unpack_fold / DEMOD_FOLD_UNPACK=1) for designs whose constant is exact.
     if (plan.conditioning == kShiftOrigin && plan.stencil_in.taps > 0) {
         double sum = 0.0;
         for (int j = 0; j < plan.stencil_in.taps; ++j) sum += (double) plan.stencil_in.h[j];
         const double re = -128.0 * sum, im = (double) plan.stencil_in.bias_im - 128.0 * sum;  // exact in double: a few floats
-        if ((double) (float) re != re || (double) (float) im != im) plan.conditioning = kShiftOriginPlain;
+        plan.fold_exact = (double) (float) re == re && (double) (float) im == im;
+        plan.conditioning = kShiftOriginPlain;
     }
 
     // Finite arithmetic is proven here, once, instead of being tested per output (see

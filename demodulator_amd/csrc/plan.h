@@ -32,8 +32,8 @@ Options options_from_params(const demod_params &p);
 // kShiftOriginPlain: the shiftOrigin unpack without folding its -128 into the complex
 // stencil's constant (kernels.hip, fold_unpack): the -q2 highpass taps (+3, -1) cancel for
 // samples with x[k+1] = 3 x[k], and there the result has to be as precise as the samples are
-// small, not as 128 + sample is.  Also chosen for -q0 designs whose folded constant
-// -128 * sum(h) is not exactly a float (build_plan).
+// small, not as 128 + sample is.  The default for -q0 with a complex stage as well (build_plan:
+// the folded form leaves the parity criterion at samples that filter to next to nothing).
 // kCorrectIq (-q1): byte minus a running DC offset that the reference carries from sample pair to
 // sample pair and from chunk to chunk (src/matrix.c:120-140); the offsets are replayed by a
 // pass of their own into a table the other kernels read (kernels.hip, correct_iq_offsets).
@@ -50,6 +50,9 @@ struct Stage {
 struct Plan {
     uint64_t chunk_bytes = 0;  // B
     int conditioning = kShiftOrigin;
+    // -q0 with a complex stage: the folded form of the unpack (kShiftOrigin in the streaming kernel) may stand in for
+    // the plain one, its constant -128 * sum(h) being exactly a float (build_plan); opt-in, demod_set_unpack_fold
+    bool fold_exact = false;
     bool prefilter = false;
     // -q2: the complex stage is highpassDc (src/matrix.c:142-157), which reads a
     // buffer of its own: zeros behind the chunk's last sample where the -L filter

@@ -71,7 +71,7 @@ def design(options: Options, which: str = "out") -> dict:
         raise DemodError(f"demod_design_query failed ({n}): {lib.demod_last_error(None).decode()}")
     return {"sos": rows[:n].copy(), "taps": taps[:n_taps.value].copy(), "bias_im": float(bias.value),
             "head_outputs": int(head.value), "magnitude_bound": float(lib.demod_design_magnitude_bound(C.byref(p))),
-            "unpack_folded": bool(lib.demod_design_unpack_folded(C.byref(p)) == 1)}
+            "unpack_fold_exact": bool(lib.demod_design_unpack_folded(C.byref(p)) == 1)}
 
 
 class Demodulator:
@@ -154,6 +154,14 @@ class Demodulator:
     @property
     def output_dtype(self):
         return np.int16 if self._lib.demod_output_bytes(self._ctx) == 2 else np.float32
+
+    def set_unpack_fold(self, on: bool = True) -> bool:
+        """Ask for the folded form of the unpack (faster, less exact at ill-conditioned samples: not the default).
+        True when the design has it (its constant is exactly a float)."""
+        rc = self._lib.demod_set_unpack_fold(self._ctx, 1 if on else 0)
+        if rc < 0:
+            self._check(rc, "demod_set_unpack_fold")
+        return rc == 0 and on
 
     def set_head_mode(self, mode: int) -> None:
         """Where chunk heads are replayed: 1 inside the streaming kernel, 0 head kernels, 2 thread-per-chunk head

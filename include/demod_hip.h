@@ -263,13 +263,19 @@ int demod_design_query(const demod_params *p, int which, float *rows6, int max_r
  * a negative error code (as a double) with the text in demod_last_error(NULL). */
 double demod_design_magnitude_bound(const demod_params *p);
 
-/* Which unpack arithmetic the streaming kernel uses for an option set with the default
- * shiftOrigin conditioning and a complex stage: 1 = the unpack hands the stencil 128 + sample
- * and the stencil's constant absorbs the -128 (one operation per sample less; chosen when that
- * constant, -128 * sum of the taps, is exactly a float -- the BASELINE designs), 0 = 128 is
- * subtracted from the samples (every other case).  Negative: error code, text in
- * demod_last_error(NULL). */
+/* The streaming kernel has two forms of the default (shiftOrigin) unpack in front of a complex
+ * stage.  The plain one subtracts 128 from the samples: the default.  The folded one hands the
+ * stencil 128 + sample and lets the stencil's constant absorb the -128: one operation per sample
+ * less (+3.6 % throughput on the north-star workload), but at samples that filter to next to
+ * nothing it differs from the reference by more than the reference's own builds differ from each
+ * other.  It is available where that constant, -128 * sum of the taps, is
+ * exactly a float (the BASELINE designs): demod_design_unpack_folded returns 1 for such an option
+ * set, 0 otherwise (negative: error code, text in demod_last_error(NULL));
+ * demod_set_unpack_fold(ctx, 1) -- or DEMOD_FOLD_UNPACK=1 in the environment at demod_create --
+ * asks for it and returns 0 when the context's design has it, 1 when it has not (the plain form
+ * stays), negative on error.  Results of the two forms differ in the last bits. */
 int demod_design_unpack_folded(const demod_params *p);
+int demod_set_unpack_fold(demod_ctx *ctx, int on);
 
 /* Seamless mode (not reference behaviour; off by default): the whole stream is
  * filtered as ONE chunk, so the look-ahead stencils run across what would be

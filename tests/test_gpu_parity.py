@@ -436,14 +436,16 @@ def test_ill_conditioned_sample_of_a_design_whose_folded_constant_is_inexact(orc
     is half an ulp away from its float (7.6e-6).  Samples (18, -10), (59, -36) filter to
     z = (-0.003, 0.010): the discriminator value there turns by error / |z|, and with the constant's
     error in every filtered sample the streaming kernel was 1.7e-3 off where the reference's own two
-    builds differ by 1e-4 (found by test_random_call_patterns, seed 1).  Such designs take the build
-    that subtracts 128 from the samples (plan.cpp build_plan); planted here at several positions of
-    several chunks, heads and chunk ends included."""
+    builds differ by 1e-4 (found by test_random_call_patterns, seed 1).  The streaming kernel
+    subtracts 128 from the samples instead (plan.cpp build_plan; the folded form is an option, and
+    not offered for this design); planted here at several positions of several chunks, heads and
+    chunk ends included."""
     opt = dm.Options(lowpass_in=9600.0, buf_size=16384)
     data = oracle.synth_bytes(0xF01D, 0, 6 * 16384).copy()
     for k in (3, 700, 1001, 4094, 8190, 8192 + 2047, 3 * 8192 + 5555):   # complex sample index of the first of the pair
         data[2 * k:2 * k + 4] = (18 + 127, -10 + 127, 59 + 127, -36 + 127)
     with dm.Demodulator(opt) as d:
+        assert not d.set_unpack_fold(True)          # asked for, not available: the plain form stays
         got = d.process_host(data)
     want = orc.process(oracle.Flags(**opt.__dict__), data)
     _check("planted |z| = 0.01", got, want, opt, data)
@@ -533,6 +535,28 @@ def test_nothing_is_written_outside_the_result(orc):
                     if fmt == "s16":
                         d.set_output_format("s16", 0.05)
                     assert torch.equal(buf[guard:guard + n_out], d.process(iq)), (kw, B, fmt, n_bytes)
+
+
+def test_folded_unpack_is_an_option_not_the_default(orc):
+    """The streaming kernel subtracts 128 from the samples by default; the folded form (the
+    stencil's constant absorbs it: 3.6 % faster, but outside the criterion at samples searched
+    for |z| ~ 0, tools/adversarial_sweep.py) has to be asked for, is offered where its constant
+    is exact (the BASELINE designs) and is inside the criterion on an ordinary stream."""
+    import torch
+    opt = dm.Options(**C3)
+    data = oracle.synth_bytes(0xF01D + 1, 0, 8 * opt.buf_size)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    iq = torch.from_numpy(data).cuda()
+    with dm.Demodulator(opt) as d:
+        plain = d.process(iq).cpu().numpy()
+        assert d.set_unpack_fold(True)
+        folded = d.process(iq).cpu().numpy()
+        assert not d.set_unpack_fold(False)
+        assert np.array_equal(d.process(iq).cpu().numpy().view(np.uint32), plain.view(np.uint32))
+    _check("plain", plain, want, opt, data)
+    _check("folded", folded, want, opt, data)
+    assert not np.array_equal(plain.view(np.uint32), folded.view(np.uint32))      # another rounding, the same result to 1e-5
+    assert float(np.abs(plain - folded).max()) < 1e-3
 
 
 def test_random_call_patterns(orc):

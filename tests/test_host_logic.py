@@ -162,11 +162,10 @@ def test_hand_counted_waits_cover_every_asm_load():
     assert b" 0 violations" in r.stdout
 
 
-def test_unpack_is_folded_only_where_the_folded_constant_is_exact():
-    """The streaming kernel folds the unpack's -128 into the complex stencil's constant only for
-    designs whose constant -128 * sum(h) (and the imaginary lane's, bias included) is exactly a
-    float: the BASELINE designs are, -L 9600 at 125 kS/s is half an ulp (7.6e-6) off and takes
-    the build that subtracts 128 from the samples."""
+def test_folded_unpack_is_offered_only_where_its_constant_is_exact():
+    """The folded form of the unpack (an option, not the default: DESIGN.md section 5) is available
+    only for designs whose constant -128 * sum(h) (and the imaginary lane's, bias included) is
+    exactly a float: the BASELINE designs are, -L 9600 at 125 kS/s is half an ulp (7.6e-6) off."""
     from fractions import Fraction
 
     def exact(opt):
@@ -176,12 +175,12 @@ def test_unpack_is_folded_only_where_the_folded_constant_is_exact():
         return all(Fraction(float(np.float32(float(c)))) == c for c in (re, im))
 
     L = dict(lowpass_in=12500.0, lowpass_out=6500.0)
-    assert dm.design(dm.Options(**L))["unpack_folded"] and exact(dm.Options(**L))                       # config 3 / the target
-    assert not dm.design(dm.Options(lowpass_in=9600.0))["unpack_folded"] and not exact(dm.Options(lowpass_in=9600.0))
-    assert not dm.design(dm.Options())["unpack_folded"]                                                  # no complex stage: nothing to fold into
-    assert not dm.design(dm.Options(mode=0x18, **L))["unpack_folded"]                                   # -q2 never folds
+    assert dm.design(dm.Options(**L))["unpack_fold_exact"] and exact(dm.Options(**L))                       # config 3 / the target
+    assert not dm.design(dm.Options(lowpass_in=9600.0))["unpack_fold_exact"] and not exact(dm.Options(lowpass_in=9600.0))
+    assert not dm.design(dm.Options())["unpack_fold_exact"]                                                  # no complex stage: nothing to fold into
+    assert not dm.design(dm.Options(mode=0x18, **L))["unpack_fold_exact"]                                   # -q2 never folds
     rng = np.random.default_rng(3)
-    n_folded = 0
+    n_exact = 0
     for _ in range(200):
         opt = dm.Options(sample_rate=float(rng.choice([96000.0, 125000.0, 192000.0, 250000.0])), lowpass_in=float(rng.integers(3000, 20000)),
                          in_degree=int(rng.integers(1, 9)), mode=0x10 | int(rng.integers(0, 4)))
@@ -189,9 +188,9 @@ def test_unpack_is_folded_only_where_the_folded_constant_is_exact():
             d = dm.design(opt)
         except dm.DemodError:
             continue
-        assert d["unpack_folded"] == exact(opt), opt
-        n_folded += d["unpack_folded"]
-    assert 10 < n_folded < 190
+        assert d["unpack_fold_exact"] == exact(opt), opt
+        n_exact += d["unpack_fold_exact"]
+    assert 10 < n_exact < 190
 
 
 def test_every_accepted_design_is_proven_finite():
