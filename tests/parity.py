@@ -42,7 +42,8 @@ cond(n): CONDITIONING CLAUSE, zero unless a complex stage runs.  The discriminat
                      recurrence with every coefficient replaced by its magnitude (abs_taps),
                      i.e. the size of the intermediate results the reference rounds
             e[k]   = COND_ULPS * 2^-24 * A[k]
-            cond(n) = sum_j |h_out[j]| * (min(pi, e/|z|) at 2(n+j) and at 2(n+j)+1)
+            cond(n) = sum_j |h_out[j]| * t(n+j),  t = asin(e/|z|) (pi once e reaches |z|) at 2n plus the same at 2n+1 -- or 2 pi where
+                     that sum reaches pi: the angle is noise there, and two values of it differ by up to 2 pi
         COND_ULPS is pinned to evidence, not chosen: tests/test_oracle_golden.py::
         test_reference_self_difference_pins_the_conditioning_clause measures the smallest
         constant under which the reference's two builds agree with each other on the BASELINE
@@ -186,9 +187,15 @@ def conditioning(dm, opt, data: np.ndarray) -> Conditioning | None:
         A = sum(a[j] * (ar[j:j + k] + ai[j:j + k]) for j in range(len(a))) + a0
         A = A + xerr * 2.0 ** 24 * sum(abs(h[j]) for j in range(len(h)))   # -q3: one rounding per sample
         e = 2.0 ** -24 * A
-        turn = np.minimum(np.pi, e / np.maximum(np.hypot(zr, zi), 1e-30))
+        # an error of length e turns a vector of length |z| by at most asin(e / |z|) -- e / |z| where that is small,
+        # which is everywhere on ordinary streams -- and by anything once e reaches |z|
+        ratio = e / np.maximum(np.hypot(zr, zi), 1e-30)
+        turn = np.where(ratio < 1.0, np.arcsin(np.minimum(ratio, 1.0)), np.pi)
         m = ln // 4
-        dd = np.concatenate([turn[0:2 * m:2] + turn[1:2 * m:2], np.zeros(len(g))])
+        # the discriminator value turns by at most turn(z[2n]) + turn(z[2n+1]); once that reaches pi the angle
+        # is noise, and two values of a noise angle in (-pi, pi] differ by up to 2 pi
+        pair = turn[0:2 * m:2] + turn[1:2 * m:2]
+        dd = np.concatenate([np.where(pair < np.pi, pair, 2.0 * np.pi), np.zeros(len(g))])
         out_cond[pos // 4:pos // 4 + m] = sum(g[j] * dd[j:j + m] for j in range(len(g)))
         # discriminator argument p = z[2n] * conj(z[2n+1]) next to the negative real axis?
         pr = zr[0:2 * m:2] * zr[1:2 * m:2] + zi[0:2 * m:2] * zi[1:2 * m:2]

@@ -67,6 +67,13 @@ while done < n_designs:
         print(f"OUTSIDE THE CRITERION ({'the reference build pair too' if both else 'THIS PATH ONLY'}; {T} taps, "
               f"{'folded' if is_folded else 'unfolded'} unpack, smallest lane value {zmin:.2e}): -S {opt.sample_rate:.0f} -L {opt.lowpass_in:.0f} "
               f"-D {opt.in_degree} -d {opt.out_degree} mode {opt.mode:#x}: {rep}" + (f" | reference pair: {self_rep}" if self_rep else ""), flush=True)
+        if os.environ.get("DEMOD_ADV_VERBOSE") == "1":
+            import parity
+            c = parity.conditioning(dm, opt, data)
+            taps = [float(t) for t in dm.design(opt)["taps"]]
+            for i in rep.first_bad[:4]:
+                print(f"    output {i}: this path {got[i]!r} reference {want[i]!r} difference {got[i] - want[i]:+.5f} = {(got[i] - want[i]) / (2 * np.pi):+.4f} x 2 pi; "
+                      f"clause {c.cond[i]:.4f}, near the axis {bool(c.near_axis[i])}, output taps {taps}", flush=True)
     if done % 50 == 0:
         print(f"{done} designs ({folded} with the folded unpack), {bad} outside the criterion; outputs {tot['n']}, needed the clause {tot['cond']}, wraps {tot['wrap']}, in band {tot['band']}", flush=True)
 print(f"adversarial sweep: {done} designs ({folded} folded), {bad} outside the criterion ({bad_self} of them with the reference's own build pair outside it too); outputs {tot['n']}, needed the clause {tot['cond']}, wraps {tot['wrap']}, in band {tot['band']}")
