@@ -15,7 +15,8 @@ ARCH    ?= gfx950
 PKG      = demodulator_amd
 SRC      = $(PKG)/csrc
 # -ffp-contract=off: the kernels spell every fused multiply-add explicitly
-# -fno-slp-vectorize: v_pk_*_f32 issue at half rate on gfx950, packing only adds moves
+# -fno-slp-vectorize: the vectoriser pairs values that are not adjacent and pays in moves (-10 % in round 1);
+#   the pairs that are (re/im of a sample, two neighbouring outputs) are written as such in kernels.hip (pf2)
 # max-ilp scheduling: interleaves the four independent atan2 chains of a row
 # (tools/microbench/valu_rate.hip, profiles/)
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize \
