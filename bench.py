@@ -79,9 +79,13 @@ WORKLOADS = {
     # fused into the kernel's store (demod_set_output_format): 2 B read + 1 B written per sample
     "c3_s16": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, out="s16",
                    desc="C3 with the fused int16 output: 2^30 samples, -L 12500 -l 6500, 3 B of HBM traffic per sample"),
-    # not the default arithmetic: the unpack's -128 folded into the complex stencil's constant (demod_set_unpack_fold;
-    # faster, but outside the parity criterion at samples that filter to next to nothing: DESIGN.md section 5)
-    "c3_fold": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, fold=True,
+    # the other forms of the complex stencil (include/demod_hip.h, demod_set_stencil_form).  The default is the
+    # stencil divided by its first tap where build_plan allows it (the BASELINE designs), the plain form otherwise.
+    "c3_plain": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, form="plain",
+                     desc="C3 with the plain form of the complex stencil (round 2's default): 2^30 samples, -L 12500 -l 6500"),
+    # not the default arithmetic: the unpack's -128 folded into the complex stencil's constant
+    # (faster than plain, but outside the parity criterion at samples that filter to next to nothing: DESIGN.md section 5)
+    "c3_fold": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, form="folded",
                     desc="C3 with the optional folded unpack (not the default arithmetic): 2^30 samples, -L 12500 -l 6500"),
 }
 PHASE_BYTES = 96 * 1024  # unaligned cut: shards start this far into a chunk
@@ -130,8 +134,11 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     d = dm.Demodulator(opt, device=dev.index)
     if seg_rows:
         d.set_segment_rows(seg_rows)
-    if wl.get("fold"):
-        d.set_unpack_fold(True)
+    if wl.get("form"):
+        if hasattr(d, "set_stencil_form"):
+            d.set_stencil_form(wl["form"])
+        elif wl["form"] == "folded":
+            d.set_unpack_fold(True)
     d.enable_timing(True)
 
     from demodulator_amd.sharding import exchange_halo, plan_shards
@@ -413,7 +420,7 @@ def main() -> int:
 
         if world == 1 and not args.no_extra:
             also = {}
-            for name in ("c3", "c2", "c3_s16", "c3_fold"):
+            for name in ("c3", "c2", "c3_s16", "c3_plain", "c3_fold"):
                 if name == args.workload:
                     continue
                 bps = 3 if WORKLOADS[name].get("out") == "s16" else ALGO_BYTES_PER_SAMPLE

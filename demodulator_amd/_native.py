@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DEMOD_HIP_LIBRARY selects another build of the same library (kernel tuning experiments)
 LIB_PATH = os.environ.get("DEMOD_HIP_LIBRARY") or os.path.join(_HERE, "libdemod_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 HALO_BYTES = 64
 ROW_BYTES = 1024
 
@@ -28,6 +28,7 @@ EXPORTS = (
     "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
     "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
     "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_design_unpack_folded", "demod_set_unpack_fold", "demod_set_head_mode",
+    "demod_set_stencil_form", "demod_stencil_form", "demod_design_stencil_form", "demod_design_normalized_constants",
     "demod_stream_depth", "demod_ring_slots_for", "demod_ring_create", "demod_ring_destroy", "demod_ring_input",
     "demod_ring_commit", "demod_ring_collect", "demod_ring_release",
     "demod_plan_shards", "demod_plan_channels", "demod_multi_create", "demod_multi_destroy", "demod_multi_devices",
@@ -143,6 +144,11 @@ def load() -> C.CDLL:
         "demod_design_magnitude_bound": (C.c_double, [C.POINTER(Params)]),
         "demod_design_unpack_folded": (C.c_int, [C.POINTER(Params)]),
         "demod_set_unpack_fold": (C.c_int, [C.c_void_p, C.c_int]),
+        "demod_set_stencil_form": (C.c_int, [C.c_void_p, C.c_int]),
+        "demod_stencil_form": (C.c_int, [C.c_void_p]),
+        "demod_design_stencil_form": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "demod_design_normalized_constants": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                       C.c_void_p, C.c_int]),
     }
     experiment = bool(os.environ.get("DEMOD_HIP_LIBRARY"))
     for name in EXPORTS:

@@ -75,6 +75,8 @@ static int create_fail(int code, const std::string &msg) {
     return code;
 }
 
+int demod_create_fail(int code, const char *msg) { return create_fail(code, msg ? msg : ""); }
+
 int demod_create(const demod_params *p, int device, demod_ctx **out) {
     if (!p || !out) return create_fail(DEMOD_E_INVAL, "null argument");
     *out = nullptr;
@@ -100,7 +102,6 @@ int demod_create(const demod_params *p, int device, demod_ctx **out) {
         return create_fail(DEMOD_E_INVAL, "device index out of range");
     }
     ctx->device = device;
-    if (const char *f = getenv("DEMOD_FOLD_UNPACK")) ctx->fold_unpack = f[0] == '1';
     if ((e = hipSetDevice(device)) != hipSuccess) {
         std::string msg = std::string("HIP setup failed: ") + hipGetErrorString(e);
         demod_destroy(ctx);
@@ -162,10 +163,30 @@ int demod_set_seamless(demod_ctx *ctx, int on) {
     return DEMOD_OK;
 }
 
-int demod_set_unpack_fold(demod_ctx *ctx, int on) {
+static int rows_conditioning(const demod_ctx *ctx);
+
+int demod_set_stencil_form(demod_ctx *ctx, int form) {
     if (!ctx) return DEMOD_E_INVAL;
-    ctx->fold_unpack = on != 0;
-    return ctx->fold_unpack && !ctx->plan.fold_exact ? 1 : DEMOD_OK;   // 1: asked for, not available for this design
+    if (form != DEMOD_STENCIL_AUTO && form != DEMOD_STENCIL_PLAIN && form != DEMOD_STENCIL_FOLDED && form != DEMOD_STENCIL_NORMALIZED) {
+        ctx->fail(DEMOD_E_INVAL, "stencil form must be DEMOD_STENCIL_AUTO, _PLAIN, _FOLDED or _NORMALIZED");
+        return DEMOD_E_INVAL;
+    }
+    ctx->stencil_form = form;
+    // 1: asked for, not available for this design (the plain form runs)
+    if (form == DEMOD_STENCIL_FOLDED) return ctx->plan.fold_exact ? DEMOD_OK : 1;
+    if (form == DEMOD_STENCIL_NORMALIZED) return ctx->plan.norm_ok ? DEMOD_OK : 1;
+    return DEMOD_OK;
+}
+
+int demod_stencil_form(const demod_ctx *ctx) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (ctx->plan.conditioning != kShiftOriginPlain || ctx->plan.stencil_in.taps == 0) return DEMOD_STENCIL_PLAIN;
+    const int c = rows_conditioning(ctx);
+    return c == kShiftOrigin ? DEMOD_STENCIL_FOLDED : c == kShiftOriginNorm ? DEMOD_STENCIL_NORMALIZED : DEMOD_STENCIL_PLAIN;
+}
+
+int demod_set_unpack_fold(demod_ctx *ctx, int on) {
+    return demod_set_stencil_form(ctx, on ? DEMOD_STENCIL_FOLDED : DEMOD_STENCIL_AUTO);
 }
 
 int demod_set_head_mode(demod_ctx *ctx, int mode) {
@@ -233,9 +254,15 @@ double demod_kernel_ms(demod_ctx *ctx, int *launches) {
 // chunks and above (one kernel per dispatch), the separate kernel ahead below that (128 KiB:
 // box-dependent, 64 KiB: 0.743 against 0.731 of peak, 16 KiB: 0.730 against 0.672, 1 KiB:
 // 0.37 against 0.27).
-// which unpack the streaming kernel's builds use: the plan's, or the folded form where it was asked for and is exact
+// which unpack and complex stencil the streaming kernel's builds use: the plan's; for the default conditioning in
+// front of a complex stage (-q0 with -L) the stencil divided by its first tap where build_plan allows it, the folded
+// form where it was asked for and its constant is exact
 static int rows_conditioning(const demod_ctx *ctx) {
-    return ctx->fold_unpack && ctx->plan.fold_exact ? (int) kShiftOrigin : ctx->plan.conditioning;
+    const Plan &pl = ctx->plan;
+    if (pl.conditioning != kShiftOriginPlain || pl.stencil_in.taps == 0) return pl.conditioning;
+    if (ctx->stencil_form == DEMOD_STENCIL_FOLDED && pl.fold_exact) return (int) kShiftOrigin;
+    if ((ctx->stencil_form == DEMOD_STENCIL_AUTO || ctx->stencil_form == DEMOD_STENCIL_NORMALIZED) && pl.norm_ok) return (int) kShiftOriginNorm;
+    return pl.conditioning;
 }
 
 static bool heads_are_fused(const demod_ctx *ctx) {
@@ -262,6 +289,12 @@ static void fill_stencils(const demod_ctx *ctx, RowLaunch &r) {
         r.fold_re = (float) (-128.0 * sum);
         r.fold_im = (float) ((double) pl.stencil_in.bias_im - 128.0 * sum);
     }
+    for (int j = 0; j < kMaxTaps; ++j) r.rho[j] = pl.rho[j];
+    r.alpha = pl.norm_alpha;
+    r.nk_re = -pl.norm_k_re;
+    r.nk_im = -pl.norm_k_im;
+    // exact: what the kernel's own alpha * 128 - k_im gives for a 0.0f sample
+    r.past_im = (float) (128.0 * (double) pl.norm_alpha - (double) pl.norm_k_im);
     r.scale = (float) (2. / 255.);
     // the chunk head is replayed inside the streaming kernel when both stages fit its
     // lane-parallel form; otherwise (more than 4 sections, highpassDc in front of -L)
@@ -425,9 +458,9 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
                                      "boundary and hold whole chunks (a short last chunk ends the stream); no seamless mode");
             return DEMOD_E_INVAL;
         }
-        const int rc = run_offsets(ctx, d_in, n_bytes, B, stream);
-        if (rc) return rc;
     }
+    // (the offsets pass consumes the stream's carried state: it runs once every check below has passed, so that a
+    // rejected call leaves the state where it was)
     const uint32_t q1_stride = (uint32_t) (B / 4);
 
     // ---- chunks shorter than one row: literal whole-chunk kernel ----------
@@ -441,6 +474,10 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
         if (tail && !eos) {
             ctx->fail(DEMOD_E_INVAL, "buffer must hold whole chunks unless it ends the stream");
             return DEMOD_E_INVAL;
+        }
+        if (q1) {
+            const int rc = run_offsets(ctx, d_in, n_bytes, B, stream);
+            if (rc) return rc;
         }
         return run_tiny(ctx, d_in, B, full, tail, d_out, stream, ctx->q1_table, q1_stride);
     }
@@ -461,6 +498,10 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
     if (offset + n_bytes > (uint64_t) 0xFFFFFFFFu * kRowBytes) {
         ctx->fail(DEMOD_E_INVAL, "buffer too large for one call (limit 4 TiB)");
         return DEMOD_E_INVAL;
+    }
+    if (q1) {
+        const int rc = run_offsets(ctx, d_in, n_bytes, B, stream);
+        if (rc) return rc;
     }
 
     // A final short chunk of less than one row (it then starts inside this
@@ -734,6 +775,29 @@ int demod_design_unpack_folded(const demod_params *p) {
     std::string err;
     if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
     return plan.fold_exact ? 1 : 0;
+}
+
+int demod_design_stencil_form(const demod_params *p, double *normalized_error, double *plain_error) {
+    if (!p) return create_fail(DEMOD_E_INVAL, "null argument");
+    Plan plan;
+    std::string err;
+    if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
+    if (normalized_error) *normalized_error = plan.norm_error + plan.norm_bias_error;
+    if (plain_error) *plain_error = plan.plain_error;
+    return plan.norm_ok ? DEMOD_STENCIL_NORMALIZED : DEMOD_STENCIL_PLAIN;
+}
+
+int demod_design_normalized_constants(const demod_params *p, float *alpha, float *k_re, float *k_im, float *rho, int max_taps) {
+    if (!p) return create_fail(DEMOD_E_INVAL, "null argument");
+    Plan plan;
+    std::string err;
+    if (!build_plan(options_from_params(*p), plan, err)) return create_fail(DEMOD_E_INVAL, err);
+    if (alpha) *alpha = plan.norm_alpha;
+    if (k_re) *k_re = plan.norm_k_re;
+    if (k_im) *k_im = plan.norm_k_im;
+    const int n = plan.stencil_in.taps;
+    for (int j = 0; rho && j < n && j < max_taps; ++j) rho[j] = plan.rho[j];
+    return plan.norm_ok ? n : 0;
 }
 
 int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed,

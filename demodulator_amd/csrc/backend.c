@@ -33,6 +33,32 @@
 
 #include "demod_hip.h"
 
+/* The layout of consumerArgs IS the ABI between the reference's host and this backend
+ * (include/matrix.h:43-57, measured on x86-64 with the reference's own build: SURVEY.md section 8 a7).
+ * A mismatch must not wait for a GPU box to show: it fails the build. */
+#if defined(__x86_64__) && defined(__linux__)
+#define DEMOD_ABI_AT(field, off) \
+    _Static_assert(offsetof(demod_consumer_args, field) == (off), "consumerArgs layout: " #field " is not at offset " #off)
+DEMOD_ABI_AT(full, 0);
+DEMOD_ABI_AT(empty, 8);
+DEMOD_ABI_AT(mutex, 16);
+DEMOD_ABI_AT(outFile, 56);
+DEMOD_ABI_AT(buf, 64);
+DEMOD_ABI_AT(exitFlag, 72);
+DEMOD_ABI_AT(mode, 76);
+DEMOD_ABI_AT(sampleRate, 80);
+DEMOD_ABI_AT(lowpassIn, 96);
+DEMOD_ABI_AT(lowpassOut, 112);
+DEMOD_ABI_AT(epsilon, 128);
+DEMOD_ABI_AT(inFilterDegree, 144);
+DEMOD_ABI_AT(outFilterDegree, 152);
+DEMOD_ABI_AT(bufSize, 160);
+_Static_assert(sizeof(demod_consumer_args) == 176, "consumerArgs layout: size is not 176");
+_Static_assert(sizeof(pthread_mutex_t) == 40 && sizeof(long double) == 16 && sizeof(size_t) == 8,
+               "consumerArgs layout: member types differ from the reference host's");
+#undef DEMOD_ABI_AT
+#endif
+
 static void die(const char *what, const char *detail) {
     fprintf(stderr, "demod backend: %s: %s\n", what, detail ? detail : "");
     exit(2);

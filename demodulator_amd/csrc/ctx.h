@@ -21,7 +21,9 @@ struct demod_ctx {
     std::string err;
 
     bool seamless = false;  // filter the whole stream as one chunk (look-ahead continues across chunk boundaries)
-    bool fold_unpack = false;  // demod_set_unpack_fold / DEMOD_FOLD_UNPACK=1: the folded unpack where Plan::fold_exact allows it
+    // demod_set_stencil_form: which form of the complex stencil the streaming kernel runs behind the shiftOrigin
+    // unpack -- DEMOD_STENCIL_AUTO: divided by its first tap where build_plan allows it (Plan::norm_ok), plain otherwise
+    int stencil_form = DEMOD_STENCIL_AUTO;
     int head_mode = -1;     // demod_set_head_mode: -1 automatic, 0 demod_heads kernel, 1 inside the streaming kernel
     uint32_t seg_rows = 0;  // 0 = automatic
     uint32_t piece_rows = 0;           // rows per demod_rows dispatch (set at creation)
@@ -76,6 +78,9 @@ struct demod_ctx {
             return DEMOD_E_HIP;                          \
         }                                                \
     } while (0)
+
+// api.cpp: records the message demod_last_error(NULL) returns and hands back `code`
+extern "C" int demod_create_fail(int code, const char *msg);
 
 // host.cpp
 void host_pipe_destroy(demod_ctx *ctx);

@@ -227,21 +227,9 @@ extern "C" {
 // ---------------------------------------------------------------------------
 // demod_process_host
 // ---------------------------------------------------------------------------
-int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, void *h_out_v, const demod_span *span) {
+static int process_host_pieces(demod_ctx *ctx, HostPipe *p, const void *h_in_v, uint64_t n_bytes, void *h_out_v, const demod_span *span) {
     char *h_out = static_cast<char *>(h_out_v);
-    if (!ctx) return DEMOD_E_INVAL;
-    if (n_bytes == 0) return DEMOD_OK;
-    if (!h_in_v || !h_out || (n_bytes & 3)) {
-        ctx->fail(DEMOD_E_INVAL, "null buffer or n_bytes not a multiple of 4");
-        return DEMOD_E_INVAL;
-    }
-    HostPipe *p = nullptr;
-    int rc = pipe_get(ctx, true, &p);
-    if (rc) return rc;
-    if (p->in_flight) {
-        ctx->fail(DEMOD_E_INVAL, "demod_process_host while submitted pieces are uncollected");
-        return DEMOD_E_INVAL;
-    }
+    int rc = DEMOD_OK;
 
     const uint8_t *h_in = static_cast<const uint8_t *>(h_in_v);
     const uint64_t ob = ctx->out_bytes();
@@ -324,6 +312,40 @@ int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, voi
         if (!jobs.empty()) p->pool->run(jobs);
     }
     return DEMOD_OK;
+}
+
+
+int demod_process_host(demod_ctx *ctx, const void *h_in_v, uint64_t n_bytes, void *h_out_v, const demod_span *span) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (n_bytes == 0) return DEMOD_OK;
+    if (!h_in_v || !h_out_v || (n_bytes & 3)) {
+        ctx->fail(DEMOD_E_INVAL, "null buffer or n_bytes not a multiple of 4");
+        return DEMOD_E_INVAL;
+    }
+    HostPipe *p = nullptr;
+    int rc = pipe_get(ctx, true, &p);
+    if (rc) return rc;
+    if (p->in_flight) {
+        ctx->fail(DEMOD_E_INVAL, "demod_process_host while submitted pieces are uncollected");
+        return DEMOD_E_INVAL;
+    }
+    rc = process_host_pieces(ctx, p, h_in_v, n_bytes, h_out_v, span);
+    if (rc) {
+        // A failure part-way leaves pieces on the three streams and stages that still name the caller's
+        // output buffer: drain the streams and forget the pieces, so that the next call neither retires
+        // stale results nor copies them to a buffer that may be gone.  (The error message stays.)
+        const std::string msg = ctx->err;
+        const int code = ctx->err_code;
+        for (hipStream_t s : {p->up, p->run, p->down})
+            if (s) (void) hipStreamSynchronize(s);
+        for (int k = 0; k < kDepth; ++k) {
+            p->st[k].out_count = 0;
+            p->st[k].dst = nullptr;
+        }
+        ctx->err = msg;
+        ctx->err_code = code;
+    }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------
@@ -426,28 +448,38 @@ int ring_submit(demod_ring *r, uint32_t count, uint64_t bytes) {
     if (!r->spare.empty()) {
         b = r->spare.back();
         r->spare.pop_back();
-    } else {
-        HIP_TRY(ctx, hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&b.computed, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&b.downloaded, hipEventDisableTiming));
     }
-    b.first = r->sent;
-    b.count = count;
-    b.bytes = bytes;
-    const uint64_t off = (b.first % r->n_slots) * r->slot;
-    const uint64_t ooff = off / 4 * ctx->out_bytes();
-    HIP_TRY(ctx, hipMemcpyAsync(r->d_in + off, r->h_in + off, bytes, hipMemcpyHostToDevice, p->up));
-    HIP_TRY(ctx, hipEventRecord(b.uploaded, p->up));
-    HIP_TRY(ctx, hipStreamWaitEvent(p->run, b.uploaded, 0));
-    // whole chunks, a short one only at the very end: every batch is a stream of its own
-    demod_span sp{};
-    sp.end_of_stream = 1;
-    const int rc = demod_process_device(ctx, r->d_in + off, bytes, r->d_out + ooff, &sp, p->run);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipEventRecord(b.computed, p->run));
-    HIP_TRY(ctx, hipStreamWaitEvent(p->down, b.computed, 0));
-    HIP_TRY(ctx, hipMemcpyAsync(r->h_out + ooff, r->d_out + ooff, bytes / 4 * ctx->out_bytes(), hipMemcpyDeviceToHost, p->down));
-    HIP_TRY(ctx, hipEventRecord(b.downloaded, p->down));
+    // Whatever fails from here on, the batch's events go back to `spare`: demod_ring_destroy
+    // destroys what is there (and in `flying`), nothing is left behind.  (A triple may be
+    // partly created: destroy skips null events.)
+    auto enqueue = [&]() -> int {
+        if (!b.uploaded) HIP_TRY(ctx, hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
+        if (!b.computed) HIP_TRY(ctx, hipEventCreateWithFlags(&b.computed, hipEventDisableTiming));
+        if (!b.downloaded) HIP_TRY(ctx, hipEventCreateWithFlags(&b.downloaded, hipEventDisableTiming));
+        b.first = r->sent;
+        b.count = count;
+        b.bytes = bytes;
+        const uint64_t off = (b.first % r->n_slots) * r->slot;
+        const uint64_t ooff = off / 4 * ctx->out_bytes();
+        HIP_TRY(ctx, hipMemcpyAsync(r->d_in + off, r->h_in + off, bytes, hipMemcpyHostToDevice, p->up));
+        HIP_TRY(ctx, hipEventRecord(b.uploaded, p->up));
+        HIP_TRY(ctx, hipStreamWaitEvent(p->run, b.uploaded, 0));
+        // whole chunks, a short one only at the very end: every batch is a stream of its own
+        demod_span sp{};
+        sp.end_of_stream = 1;
+        const int rc = demod_process_device(ctx, r->d_in + off, bytes, r->d_out + ooff, &sp, p->run);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(b.computed, p->run));
+        HIP_TRY(ctx, hipStreamWaitEvent(p->down, b.computed, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(r->h_out + ooff, r->d_out + ooff, bytes / 4 * ctx->out_bytes(), hipMemcpyDeviceToHost, p->down));
+        HIP_TRY(ctx, hipEventRecord(b.downloaded, p->down));
+        return DEMOD_OK;
+    };
+    const int rc = enqueue();
+    if (rc) {
+        r->spare.push_back(b);
+        return rc;
+    }
     r->flying.push_back(b);
     r->sent += count;
     r->n_batches++;

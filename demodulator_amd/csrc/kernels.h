@@ -43,6 +43,12 @@ struct RowLaunch {
     float hin[kMaxTaps];
     float bias_im;
     float fold_re, fold_im;  // constant terms of the complex stencil with the unpack's -128 folded in
+    // kShiftOriginNorm: taps over the first one; the unpack alpha * (sample + 128) + (nk_re, nk_im), nk = -(128 alpha,
+    // alpha (128 - s)); a sample past a chunk end (0.0f) is (0, past_im) there
+    float rho[kMaxTaps];
+    float alpha;
+    float nk_re, nk_im;
+    float past_im;
     float hout[kMaxTaps];
     float scale;           // normalizeInput: (float)(2./255.)
     uint32_t out_s16;      // results leave as int16: clamp(y * out_scale, -1, 1) * 32767 rounded (host side: picks the build)

@@ -148,8 +148,10 @@ __device__ __forceinline__ void fast_atan2_pair(float y0, float x0, float y1, fl
     const uint32_t xb0 = __float_as_uint(x0), yb0 = __float_as_uint(y0), xb1 = __float_as_uint(x1), yb1 = __float_as_uint(y1);
     const float t0 = fabsf(x0) - fabsf(y0), t1 = fabsf(x1) - fabsf(y1);
     const uint32_t sw0 = (uint32_t) (__float_as_int(t0) >> 31), sw1 = (uint32_t) (__float_as_int(t1) >> 31);
-    const float hi0 = fabsf(__uint_as_float(bit_select(sw0, yb0, xb0))), lo0 = fabsf(__uint_as_float(bit_select(sw0, xb0, yb0)));
-    const float hi1 = fabsf(__uint_as_float(bit_select(sw1, yb1, xb1))), lo1 = fabsf(__uint_as_float(bit_select(sw1, xb1, yb1)));
+    const float lo0 = fabsf(__uint_as_float(bit_select(sw0, xb0, yb0)));
+    const float lo1 = fabsf(__uint_as_float(bit_select(sw1, xb1, yb1)));
+    const float hi0 = fabsf(__uint_as_float(bit_select(sw0, yb0, xb0)));
+    const float hi1 = fabsf(__uint_as_float(bit_select(sw1, yb1, xb1)));
     const pf2 q = {fmul_legacy(lo0, __builtin_amdgcn_rcpf(hi0)), fmul_legacy(lo1, __builtin_amdgcn_rcpf(hi1))};
     const pf2 s = q * q;
     auto k = [](float c) { return pf2{c, c}; };
@@ -294,21 +296,22 @@ struct Halo {
 //     operations per value and row; used by the bounds-checked build.
 //
 // `edge`: this row starts a chunk.  What its lane 0 hands to the row before it is then not its
-// own values but what the reference finds past a chunk's end: 0.0f samples (`past` = 128 where
-// the unpack bias is folded), 0.0f discriminator outputs.  (A segment spans chunks when chunks
+// own values but what the reference finds past a chunk's end: 0.0f samples (`past_re`, `past_im`:
+// 128 where the unpack bias is folded, (0, s) where the stencil is divided by its first tap), 0.0f
+// discriminator outputs.  (A segment spans chunks when chunks
 // are shorter than a segment.)
 struct RegisterExchange {
     Halo &halo;
     bool edge = false;
-    float past = 0.f;
+    float past_re = 0.f, past_im = 0.f;
     template <int N>
     __device__ __forceinline__ void next_x(float *xr, float *xi) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             xr[8 + j] = from_next_lane(xr[j], halo.xr[j]);
             xi[8 + j] = from_next_lane(xi[j], halo.xi[j]);
-            halo.xr[j] = edge ? past : wave_first(xr[j]);
-            halo.xi[j] = edge ? past : wave_first(xi[j]);
+            halo.xr[j] = edge ? past_re : wave_first(xr[j]);
+            halo.xi[j] = edge ? past_im : wave_first(xi[j]);
         }
     }
     template <int N>
@@ -335,14 +338,14 @@ struct LdsExchange {
     lds_float *wr_d;
     const lds_float *rd_d;
     bool edge0 = false;  // lane 0 of a row that starts a chunk: publishes past-the-end values (see RegisterExchange)
-    float past = 0.f;
+    float past_re = 0.f, past_im = 0.f;
     template <int N>
     __device__ __forceinline__ void next_x(float *xr, float *xi) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             f32x2 v;
-            v.x = edge0 ? past : xr[j];
-            v.y = edge0 ? past : xi[j];
+            v.x = edge0 ? past_re : xr[j];
+            v.y = edge0 ? past_im : xi[j];
             *reinterpret_cast<__attribute__((address_space(3))) f32x2 *>(wr_x + 2 * j) = v;
         }
         __builtin_amdgcn_wave_barrier();
@@ -389,6 +392,23 @@ template <int TIN, int COND, bool RAGGED>
 constexpr bool fold_unpack() {
     return TIN > 0 && COND == kShiftOrigin;
 }
+// The complex stencil divided by its first tap (plan.h, kShiftOriginNorm): z / h0 = X[k] + sum_j rho_j X[k+j]
+// with X = (re, im + s) straight from the unpack's subtraction of (128, 128 - s).
+template <int TIN, int COND>
+constexpr bool norm_stencil() {
+    return TIN > 0 && COND == kShiftOriginNorm;
+}
+template <int COND>
+constexpr bool shift_origin() {
+    return COND == kShiftOrigin || COND == kShiftOriginPlain || COND == kShiftOriginNorm;
+}
+template <int T>
+__device__ __forceinline__ float stencil_norm(const float *rho, const float *v) {
+    float acc = v[0];
+#pragma unroll
+    for (int j = 1; j < T; ++j) acc = fmaf(rho[j], v[j], acc);
+    return acc;
+}
 
 // One row for one lane: 16 input bytes (8 complex samples) -> 4 outputs.
 // `valid` = usable bytes of this lane's 16 (16 unless RAGGED); `ex` supplies the
@@ -401,20 +421,37 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
     constexpr int ND = 4 + TOUT - 1;
     float xr[NX], xi[NX];
     constexpr bool FOLD = fold_unpack<TIN, COND, RAGGED>();
+    constexpr bool NORM = norm_stencil<TIN, COND>();
     // the plain shiftOrigin unpack of the streaming builds takes its 128 off (re, im) pairs: eight
-    // v_pk_add_f32 instead of sixteen subtractions (the same values)
-    constexpr bool PAIRS = !RAGGED && !FOLD && (COND == kShiftOrigin || COND == kShiftOriginPlain);
-    unpack_dword<COND, FOLD || PAIRS>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
-    unpack_dword<COND, FOLD || PAIRS>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
-    unpack_dword<COND, FOLD || PAIRS>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
-    unpack_dword<COND, FOLD || PAIRS>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
-    if constexpr (PAIRS) {
+    // v_pk_add_f32 instead of sixteen subtractions (the same values); the normalised stencil's unpack
+    // takes (128, 128 - s) off them
+    constexpr bool PAIRS = !RAGGED && !FOLD && shift_origin<COND>();
+    constexpr bool RAW = FOLD || PAIRS || NORM;  // unpack_dword hands back sample + 128
+    unpack_dword<COND, RAW>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+    unpack_dword<COND, RAW>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+    unpack_dword<COND, RAW>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+    unpack_dword<COND, RAW>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+    if constexpr (PAIRS && NORM) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const pf2 p = fma2(pf2{xr[k], xi[k]}, pf2{a.alpha, a.alpha}, pf2{a.nk_re, a.nk_im});  // exact (plan.cpp)
+            xr[k] = p.x;
+            xi[k] = p.y;
+        }
+    } else if constexpr (PAIRS) {
         const float k128 = opaque_128();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const pf2 p = pf2{xr[k], xi[k]} - pf2{k128, k128};
             xr[k] = p.x;
             xi[k] = p.y;
+        }
+    } else if constexpr (NORM) {
+        // (bounds-checked build: the same operations, one by one)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            xr[k] = fmaf(xr[k], a.alpha, a.nk_re);
+            xi[k] = fmaf(xi[k], a.alpha, a.nk_im);
         }
     }
     if constexpr (COND == kCorrectIq) {
@@ -451,7 +488,7 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
         for (int k = 0; k < 8; ++k) {
             const bool ok = 2 * k < valid;
             xr[k] = ok ? xr[k] : (FOLD ? 128.f : 0.f);
-            xi[k] = ok ? xi[k] : (FOLD ? 128.f : 0.f);
+            xi[k] = ok ? xi[k] : (FOLD ? 128.f : NORM ? a.past_im : 0.f);
         }
     }
 
@@ -465,6 +502,11 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
         for (int k = 0; k < 8; ++k) {
             if constexpr (TIN == 0) {
                 z[k] = pf2{xr[k], xi[k]};
+            } else if constexpr (NORM) {
+                pf2 acc = pf2{xr[k], xi[k]};
+#pragma unroll
+                for (int j = 1; j < TIN; ++j) acc = fma2(pf2{a.rho[j], a.rho[j]}, pf2{xr[k + j], xi[k + j]}, acc);
+                z[k] = acc;
             } else if constexpr (FOLD) {
                 pf2 acc = fma2(pf2{a.hin[0], a.hin[0]}, pf2{xr[k], xi[k]}, pf2{a.fold_re, a.fold_im});
 #pragma unroll
@@ -487,7 +529,10 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
         float zr[8], zi[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if constexpr (FOLD) {
+            if constexpr (NORM) {
+                zr[k] = stencil_norm<TIN>(a.rho, &xr[k]);
+                zi[k] = stencil_norm<TIN>(a.rho, &xi[k]);
+            } else if constexpr (FOLD) {
                 zr[k] = stencil<TIN>(a.hin, &xr[k], a.fold_re);
                 zi[k] = stencil<TIN>(a.hin, &xi[k], a.fold_im);
             } else {
@@ -515,8 +560,11 @@ __device__ __forceinline__ void process_row(const uint4 w, const RowLaunch &a, E
 // Look-ahead a segment needs from the row after it: only that row's lane-0
 // values (its first complex samples and first discriminator outputs), which
 // depend on its first lanes alone.  For the common short stencils they depend on
-// lane 0's own 16 bytes, so only that part of the row is computed; the long
-// stencils fall back to a full row (its own look-ahead is irrelevant).
+// lane 0's own 16 bytes: every lane has read THOSE bytes (one broadcast request), so every
+// lane computes the same values and nothing has to be fetched from lane 0; only the samples
+// that are read are unpacked.  The long stencils fall back to a full row (its own look-ahead
+// is irrelevant), lane 0's results broadcast.  Same operations on the same values as
+// process_row performs for that row's lane 0.
 template <int TIN, int TOUT, int COND>
 __device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunch &a, Halo &halo) {
     constexpr int ND = TOUT - 1;                        // discriminator outputs to hand back
@@ -524,37 +572,53 @@ __device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunc
     if constexpr (NX <= 8 && (TIN > 0 ? TIN - 1 : 0) <= 8) {
         float xr[8], xi[8];
         constexpr bool FOLD = fold_unpack<TIN, COND, false>();
-        unpack_dword<COND, FOLD>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
-        if constexpr (NX > 2) unpack_dword<COND, FOLD>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
-        if constexpr (NX > 4) unpack_dword<COND, FOLD>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
-        if constexpr (NX > 6) unpack_dword<COND, FOLD>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+        constexpr bool NORM = norm_stencil<TIN, COND>();
+        constexpr bool PAIRS = !FOLD && shift_origin<COND>();
+        constexpr bool RAW = FOLD || PAIRS;
+        unpack_dword<COND, RAW>(w.x, a.scale, xr[0], xi[0], xr[1], xi[1]);
+        if constexpr (NX > 2) unpack_dword<COND, RAW>(w.y, a.scale, xr[2], xi[2], xr[3], xi[3]);
+        if constexpr (NX > 4) unpack_dword<COND, RAW>(w.z, a.scale, xr[4], xi[4], xr[5], xi[5]);
+        if constexpr (NX > 6) unpack_dword<COND, RAW>(w.w, a.scale, xr[6], xi[6], xr[7], xi[7]);
+        pf2 x[NX > 0 ? NX : 1];
+        if constexpr (PAIRS && NORM) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) x[k] = fma2(pf2{xr[k], xi[k]}, pf2{a.alpha, a.alpha}, pf2{a.nk_re, a.nk_im});
+        } else if constexpr (PAIRS) {
+            const float k128 = opaque_128();
+#pragma unroll
+            for (int k = 0; k < NX; ++k) x[k] = pf2{xr[k], xi[k]} - pf2{k128, k128};
+        } else {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) x[k] = pf2{xr[k], xi[k]};
+        }
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
-            float d;
-            if constexpr (TIN > 0) {
-                float ar, ai, br, bi;
-                if constexpr (FOLD) {
-                    ar = stencil<TIN>(a.hin, &xr[2 * j], a.fold_re);
-                    ai = stencil<TIN>(a.hin, &xi[2 * j], a.fold_im);
-                    br = stencil<TIN>(a.hin, &xr[2 * j + 1], a.fold_re);
-                    bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.fold_im);
+            pf2 z[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 2 * j + e;
+                if constexpr (TIN == 0) {
+                    z[e] = x[k];
+                } else if constexpr (NORM) {
+                    pf2 acc = x[k];
+#pragma unroll
+                    for (int t = 1; t < TIN; ++t) acc = fma2(pf2{a.rho[t], a.rho[t]}, x[k + t], acc);
+                    z[e] = acc;
                 } else {
-                    ar = stencil<TIN>(a.hin, &xr[2 * j], 0.f);   // (from +0.0f, as process_row's pairs)
-                    ai = stencil<TIN>(a.hin, &xi[2 * j], a.bias_im);
-                    br = stencil<TIN>(a.hin, &xr[2 * j + 1], 0.f);
-                    bi = stencil<TIN>(a.hin, &xi[2 * j + 1], a.bias_im);
+                    pf2 acc = fma2(pf2{a.hin[0], a.hin[0]}, x[k], FOLD ? pf2{a.fold_re, a.fold_im} : pf2{0.f, a.bias_im});
+#pragma unroll
+                    for (int t = 1; t < TIN; ++t) acc = fma2(pf2{a.hin[t], a.hin[t]}, x[k + t], acc);
+                    z[e] = acc;
                 }
-                d = discriminate(ar, ai, br, bi);
-            } else {
-                d = discriminate(xr[2 * j], xi[2 * j], xr[2 * j + 1], xi[2 * j + 1]);
             }
-            halo.d[j] = wave_first(d);
+            const pf2 arg = discriminator_argument(z[0], z[1]);
+            halo.d[j] = fast_atan2(arg.y, arg.x);
         }
         if constexpr (TIN > 1) {
 #pragma unroll
             for (int j = 0; j < TIN - 1; ++j) {
-                halo.xr[j] = wave_first(xr[j]);
-                halo.xi[j] = wave_first(xi[j]);
+                halo.xr[j] = x[j].x;
+                halo.xi[j] = x[j].y;
             }
         }
     } else {
@@ -563,6 +627,20 @@ __device__ __forceinline__ void next_row_lookahead(const uint4 w, const RowLaunc
         process_row<TIN, TOUT, COND, false>(w, a, ex, 16, kAtanLead, unused);
     }
 }
+
+// 1 KiB of bytes that unpack to 0.0f samples (shiftOrigin: byte 127): what a segment that ends a
+// chunk "reads" as the row after it -- the reference's buffers hold zeros there.  Such a row's
+// first discriminator outputs are +0.0f too (samples (0, c), (0, c) with the complex stage's
+// constant c: zr = c c >= +0, zj = +0), so the look-ahead of a chunk end is computed like any
+// other and no lane has to select.  (Not for the folded unpack, whose stencil of zeros is not
+// exactly its constant, and not for normalizeInput, which has no byte for 0.0f.)
+struct PastEndBytes {
+    uint32_t w[kRowBytes / 4];
+    constexpr PastEndBytes() : w() {
+        for (uint32_t i = 0; i < kRowBytes / 4; ++i) w[i] = 0x7F7F7F7Fu;
+    }
+};
+__device__ __attribute__((aligned(16))) const PastEndBytes kPastEndRow = PastEndBytes();
 
 __device__ __forceinline__ uint4 load_row16(const uint8_t *row_base, uint32_t lane) {
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row_base) + lane);
@@ -624,6 +702,26 @@ template <bool S16, bool WIDE = false>
 __device__ __forceinline__ void store_quad(void *dst, const float (&y)[4], float scale) {
     if constexpr (S16) store_out8_s16(dst, y, scale);
     else store_out16<WIDE>(static_cast<float *>(dst), y);
+}
+// The same for a row of the streaming kernel: `row` is wave-uniform (it travels in scalar
+// registers), `lane_off` this lane's byte offset in the row.  Spelled out: hipcc turns
+// uniform-plus-lane pointer arithmetic into a 64-bit VALU add per store.  The wait states are
+// the ones a VALU write to the data registers of a wide store needs behind it.
+template <bool S16, bool WIDE>
+__device__ __forceinline__ void store_row(char *row, uint32_t lane_off, const float (&y)[4], float scale) {
+    if constexpr (S16) {
+        u32x2 v;
+        v.x = to_s16_pair(y[0], y[1], scale);
+        v.y = to_s16_pair(y[2], y[3], scale);
+        asm volatile("global_store_dwordx2 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
+    } else {
+        f32x4 v;
+        v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
+        if constexpr (DEMOD_STORE_POLICY_ID != 5 && (WIDE || DEMOD_STORE_POLICY_ID != 0))
+            asm volatile("global_store_dwordx4 %0, %1, %2" DEMOD_STORE_POLICY "\n\ts_nop 1" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
+        else
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(lane_off), "v"(v), "s"(row) : "memory");
+    }
 }
 template <bool S16>
 __device__ __forceinline__ char *out_address(void *base, uint64_t index) {
@@ -863,11 +961,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
 
     if constexpr (RAGGED) {
         // bounds-checked build (stream end only): one row at a time
-        if constexpr (fold_unpack<TIN, COND, true>()) {
+        // a sample past the end (0.0f) in the domain the stencil works in
+        const float past_re = fold_unpack<TIN, COND, true>() ? 128.f : 0.f;
+        const float past_im = fold_unpack<TIN, COND, true>() ? 128.f : norm_stencil<TIN, COND>() ? a.past_im : 0.f;
 #pragma unroll
-            for (int j = 0; j < kMaxTaps - 1; ++j) halo.xr[j] = halo.xi[j] = 128.f;  // 0.0f in the folded domain
+        for (int j = 0; j < kMaxTaps - 1; ++j) {
+            halo.xr[j] = past_re;
+            halo.xi[j] = past_im;
         }
-        RegisterExchange ex{halo, false, fold_unpack<TIN, COND, true>() ? 128.f : 0.f};
+        RegisterExchange ex{halo, false, past_re, past_im};
         auto q1_row = [&](uint32_t r) -> Q1Row {
             if constexpr (COND != kCorrectIq) return Q1Row{nullptr, 0, 0};
             const uint32_t chunk = (g0 + r) >> a.rpc_log2;
@@ -905,19 +1007,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
         // advancing window of memory are what reaches the HBM streaming rate
         // (tools/microbench/stream_copy.hip: 1-4 rows per wavefront 0.80-0.83 of
         // peak, 32 rows 0.74, 256 rows 0.65).
-        // a sample past the chunk end: 0.0f, which is 128 where the unpack bias is folded
-        constexpr float kPastEnd = fold_unpack<TIN, COND, false>() ? 128.f : 0.f;
+        // a sample past the chunk end: 0.0f, which is 128 where the unpack bias is folded and
+        // (0, s) where the stencil is divided by its first tap
+        const float past_re = fold_unpack<TIN, COND, false>() ? 128.f : 0.f;
+        const float past_im = fold_unpack<TIN, COND, false>() ? 128.f : norm_stencil<TIN, COND>() ? a.past_im : 0.f;
         const bool need_next = (ge & rpc_mask) != 0u;             // segment ends inside a chunk
         const bool next_in_buffer = need_next && re < a.rows_readable;  // ... and the next row is ours to read
         const bool next_is_halo = need_next && !next_in_buffer && a.halo != nullptr;
         // The row after the segment is asked for first (it is needed first), from
         // wherever it lives: this buffer, the next shard's first DEMOD_HALO_BYTES
         // bytes, or -- at a chunk or stream end, where the reference's buffers hold
-        // zeros -- nowhere (row rb is read instead and the result discarded, so
-        // that the prologue has no branch around a load).
+        // zeros -- a row of bytes that unpack to zeros (kPastEndRow; the builds that have no
+        // such byte read row rb instead and select afterwards): the prologue has no branch
+        // around a load.
         const bool have_next = next_in_buffer || next_is_halo;
+        constexpr bool kZeroRow = shift_origin<COND>() && !fold_unpack<TIN, COND, false>();
         const uint8_t *nbase = next_in_buffer ? a.in + (uint64_t) re * kRowBytes
                                : next_is_halo ? a.halo
+                               : kZeroRow     ? reinterpret_cast<const uint8_t *>(kPastEndRow.w)
                                               : a.in + (uint64_t) rb * kRowBytes;
         // Only lane 0 of that row matters when the look-ahead fits its 16 bytes (the
         // short stencils): then every lane reads lane 0's bytes -- one broadcast
@@ -960,6 +1067,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
         // generated assembly against these rules.
         constexpr int nx = 2 * (TOUT - 1) + (TIN > 0 ? TIN - 1 : 0);
         const uint8_t *np = nbase + 16u * nlane;
+        // Rows are addressed as (wave-uniform base in scalar registers) + (this lane's 16 bytes
+        // of a row, one VGPR for every load and every float32 store of the segment): no
+        // per-row 64-bit address arithmetic on the VALU.
+        const uint32_t lane_in = 16u * lane;
+        const uint32_t lane_out = (S16 ? 8u : 16u) * lane;
         // The body exists twice: FULL (all kGroup rows: every segment but the first and last of
         // a launch, and every one when chunks are at least kGroup rows long) is straight-line
         // code, so that hipcc schedules across the rows; the other form serves a clipped
@@ -977,8 +1089,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
 #pragma unroll
             for (int k = 0; k < kGroup; ++k) {
                 const uint32_t row = (FULL || re >= rb + 1u + (uint32_t) k) ? re - 1u - (uint32_t) k : rb;
-                const uint8_t *rp = a.in + (uint64_t) row * kRowBytes + 16u * lane;
-                asm volatile("global_load_dwordx4 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qa[k]) : "v"(rp) : "memory");
+                const uint8_t *rp = a.in + (uint64_t) row * kRowBytes;
+                asm volatile("global_load_dwordx4 %0, %1, %2" DEMOD_LOAD_POLICY : "=v"(qa[k]) : "v"(lane_in), "s"(rp) : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
             // the look-ahead row was asked for first: kGroup younger loads may stay in flight
@@ -993,13 +1105,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
                 Halo h = halo;
                 next_row_lookahead<TIN, TOUT, COND>(qn, a, h);
                 // the first row processed uses line 0 and, in lane 63, slot 0 of line 1
+                // (kZeroRow: a segment that ends its chunk has read zeros and computed the
+                // past-the-end values like any others)
 #pragma unroll
                 for (int j = 0; j < kExX / 2; ++j) {
-                    wr_x[1][2 * j] = have_next ? h.xr[j] : kPastEnd;
-                    wr_x[1][2 * j + 1] = have_next ? h.xi[j] : kPastEnd;
+                    wr_x[1][2 * j] = (kZeroRow || have_next) ? h.xr[j] : past_re;
+                    wr_x[1][2 * j + 1] = (kZeroRow || have_next) ? h.xi[j] : past_im;
                 }
 #pragma unroll
-                for (int j = 0; j < TOUT - 1; ++j) wr_d[1][j] = have_next ? h.d[j] : 0.f;
+                for (int j = 0; j < TOUT - 1; ++j) wr_d[1][j] = (kZeroRow || have_next) ? h.d[j] : 0.f;
             }
             float lead = kAtanLead;
             asm volatile("" : "+v"(lead));  // one register for the whole segment, see fast_atan2
@@ -1014,11 +1128,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
                 float y[4];
                 LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1],
-                               SPAN && lane == 0u && ((g0 + r) & rpc_mask) == 0u, kPastEnd};
+                               SPAN && lane == 0u && ((g0 + r) & rpc_mask) == 0u, past_re, past_im};
                 process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
                 // (the first lanes of a chunk's first row hold interior-formula values for
                 // outputs that are not interior: chunk_head / demod_heads overwrites them)
-                store_quad<S16, TIN == 0>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs + 4u * lane), y, a.out_scale);
+                store_row<S16, TIN == 0>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs), lane_out, y, a.out_scale);
             }
             if constexpr (!FULL) {
                 // the stand-in loads of the missing rows land in registers hipcc believes free
@@ -1648,12 +1762,16 @@ int launch_rows_t(const RowLaunch &a, hipStream_t s) {
 
 template <int COND>
 int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
+#ifdef DEMOD_LAB
+    // laboratory build (tools/isa_table.py --lab, A/B variants): only the BASELINE configurations' kernels
+    if (tin == 2 && tout == 2) return launch_rows_t<2, 2, COND>(a, s);
+    if constexpr (COND != kShiftOriginNorm)
+        if (tin == 0 && tout == 2) return launch_rows_t<0, 2, COND>(a, s);
+    return -1;
+#else
     // specialised stencil lengths for the common designs, a 5-tap build for the rest
     if (tin <= 3 && tout <= 3) {
         switch (tin * 4 + tout) {
-        case 0 * 4 + 1: return launch_rows_t<0, 1, COND>(a, s);
-        case 0 * 4 + 2: return launch_rows_t<0, 2, COND>(a, s);
-        case 0 * 4 + 3: return launch_rows_t<0, 3, COND>(a, s);
         case 1 * 4 + 1: return launch_rows_t<1, 1, COND>(a, s);
         case 1 * 4 + 2: return launch_rows_t<1, 2, COND>(a, s);
         case 1 * 4 + 3: return launch_rows_t<1, 3, COND>(a, s);
@@ -1665,10 +1783,22 @@ int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
         case 3 * 4 + 3: return launch_rows_t<3, 3, COND>(a, s);
         default: break;
         }
+        // (the stencil divided by its first tap exists with a complex stage only)
+        if constexpr (COND != kShiftOriginNorm) {
+            switch (tin * 4 + tout) {
+            case 0 * 4 + 1: return launch_rows_t<0, 1, COND>(a, s);
+            case 0 * 4 + 2: return launch_rows_t<0, 2, COND>(a, s);
+            case 0 * 4 + 3: return launch_rows_t<0, 3, COND>(a, s);
+            default: break;
+            }
+        }
     }
     // zero-padded taps make the long stencils exact for any shorter design
-    if (tin == 0) return launch_rows_t<0, kMaxTaps, COND>(a, s);
+    if constexpr (COND != kShiftOriginNorm) {
+        if (tin == 0) return launch_rows_t<0, kMaxTaps, COND>(a, s);
+    }
     return launch_rows_t<kMaxTaps, kMaxTaps, COND>(a, s);
+#endif
 }
 
 }  // namespace
@@ -1696,14 +1826,19 @@ int launch_rows_q1(const RowLaunch &a, hipStream_t s) {
 int launch_rows(const RowLaunch &a, int taps_in, int taps_out, int conditioning, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.n_rows == 0) return 0;
+    if (conditioning == kShiftOriginNorm && taps_in > 0) return launch_rows_c<kShiftOriginNorm>(a, taps_in, taps_out, s);
+    if (conditioning == kShiftOriginPlain) return launch_rows_c<kShiftOriginPlain>(a, taps_in, taps_out, s);
+#ifdef DEMOD_LAB
+    return conditioning == kShiftOrigin ? launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s) : -1;
+#else
     if (conditioning == kCorrectIq) {
         if (taps_in == 0 && taps_out == 2) return launch_rows_q1<0, 2>(a, s);
         if (taps_in == 2 && taps_out == 2) return launch_rows_q1<2, 2>(a, s);
         return taps_in == 0 ? launch_rows_q1<0, kMaxTaps>(a, s) : launch_rows_q1<kMaxTaps, kMaxTaps>(a, s);
     }
     if (conditioning == kNormalize) return launch_rows_c<kNormalize>(a, taps_in, taps_out, s);
-    if (conditioning == kShiftOriginPlain) return launch_rows_c<kShiftOriginPlain>(a, taps_in, taps_out, s);
     return launch_rows_c<kShiftOrigin>(a, taps_in, taps_out, s);
+#endif
 }
 
 namespace {

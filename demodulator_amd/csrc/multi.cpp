@@ -156,6 +156,14 @@ int demod_multi_create(const demod_params *p, const int *devices, int n_devices,
         }
         m->devices.push_back(devices[i]);
         m->ctx.push_back(c);
+        if (c->plan.conditioning == kCorrectIq) {
+            // -q1: correctIq's running offsets belong to ONE stream walked in order (src/matrix.c:125 static state).
+            // Every shard but the first would start them from zero, and a device's channels, laid back to back in
+            // one call, would hand them from one channel to the next: neither is what the reference computes.
+            demod_multi_destroy(m);
+            return demod_create_fail(DEMOD_E_INVAL, "-q1 (correctIq) carries its offsets through one stream in order: it cannot be "
+                                                    "sharded or batched over devices (demod_multi_*); use one context per stream");
+        }
         hipStream_t s = nullptr;
         uint8_t *h = nullptr;
         if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||

@@ -37,7 +37,18 @@ Options options_from_params(const demod_params &p);
 // kCorrectIq (-q1): byte minus a running DC offset that the reference carries from sample pair to
 // sample pair and from chunk to chunk (src/matrix.c:120-140); the offsets are replayed by a
 // pass of their own into a table the other kernels read (kernels.hip, correct_iq_offsets).
-enum Conditioning : int { kShiftOrigin = 0, kShiftOriginPlain = 1, kNormalize = 3, kCorrectIq = 4 };
+// kShiftOriginNorm (streaming kernel only, round 3): the complex stencil divided by its first tap,
+//   z / h0 = x[k] + rho_1 x[k+1] (+ rho_2 x[k+2] ...) + bias / h0,     rho_j = h_j / h_0,
+// which is all the discriminator needs -- it takes the ARGUMENT of z[2n] conj(z[2n+1]), and a positive
+// factor on both samples does not turn it.  The first tap costs no operation, and the constant
+// rides on the unpack: X = alpha * (sample + 128) - (128 alpha, alpha (128 - s)) = alpha (x, x + s),
+// s = bias / sum(h), one packed fused multiply-add where the plain form has a packed subtraction --
+// exact, alpha chosen by build_plan so that its constants are floats (plan.cpp).  One fused
+// multiply-add per tap less, ONE rounding per filtered sample instead of TIN, on intermediates no
+// larger than the samples.  What it is not is the reference's own coefficient set: the rho_j are
+// floats, so the taps applied are the design's up to their rounding -- build_plan prices that
+// (Plan::norm_error) against the rounding the plain form commits and allows the form where it is smaller.
+enum Conditioning : int { kShiftOrigin = 0, kShiftOriginPlain = 1, kShiftOriginNorm = 2, kNormalize = 3, kCorrectIq = 4 };
 
 struct Stage {
     int sections = 0;                 // S = ceil(degree / 2)
@@ -53,6 +64,15 @@ struct Plan {
     // -q0 with a complex stage: the folded form of the unpack (kShiftOrigin in the streaming kernel) may stand in for
     // the plain one, its constant -128 * sum(h) being exactly a float (build_plan); opt-in, demod_set_unpack_fold
     bool fold_exact = false;
+    // -q0 with a complex stage: the stencil divided by its first tap (kShiftOriginNorm).  rho[j] = (float)(h[j] / h[0]);
+    // the unpack is X = alpha * (byte + 128-complement) - (k_re, k_im) = alpha (x, x + s), exact, with k_re = 128 alpha and
+    // alpha searched so that k_im = alpha (128 - s) is a float to within norm_bias_error (in the reference's units of a
+    // filtered sample); norm_error / plain_error: what the remaining roundings of the two forms can move a full-scale
+    // filtered sample by (plan.cpp, price_normalised_stencil); norm_ok: the form is allowed
+    float rho[kMaxTaps] = {};
+    float norm_alpha = 1.f, norm_k_re = 128.f, norm_k_im = 128.f;
+    double norm_error = 0, plain_error = 0, norm_bias_error = 0;
+    bool norm_ok = false;
     bool prefilter = false;
     // -q2: the complex stage is highpassDc (src/matrix.c:142-157), which reads a
     // buffer of its own: zeros behind the chunk's last sample where the -L filter

@@ -71,7 +71,29 @@ def design(options: Options, which: str = "out") -> dict:
         raise DemodError(f"demod_design_query failed ({n}): {lib.demod_last_error(None).decode()}")
     return {"sos": rows[:n].copy(), "taps": taps[:n_taps.value].copy(), "bias_im": float(bias.value),
             "head_outputs": int(head.value), "magnitude_bound": float(lib.demod_design_magnitude_bound(C.byref(p))),
-            "unpack_fold_exact": bool(lib.demod_design_unpack_folded(C.byref(p)) == 1)}
+            "unpack_fold_exact": bool(lib.demod_design_unpack_folded(C.byref(p)) == 1), **_stencil_form(lib, p)}
+
+
+STENCIL_FORMS = {"auto": 0, "plain": 1, "folded": 2, "normalized": 3}
+
+
+def _stencil_form(lib, p) -> dict:
+    """Which form of the complex stencil the streaming kernel gives this option set by default, and the two error
+    bounds build_plan compared (include/demod_hip.h, demod_design_stencil_form)."""
+    fn = getattr(lib, "demod_design_stencil_form", None)
+    if fn is None:      # absent from older builds selected with DEMOD_HIP_LIBRARY
+        return {}
+    en, ep = C.c_double(0), C.c_double(0)
+    form = fn(C.byref(p), C.byref(en), C.byref(ep))
+    out = {"stencil_form": {1: "plain", 3: "normalized"}.get(form, "plain"), "normalized_error": float(en.value),
+           "plain_error": float(ep.value)}
+    fn = getattr(lib, "demod_design_normalized_constants", None)
+    if fn is not None:
+        a, kr, ki = C.c_float(0), C.c_float(0), C.c_float(0)
+        rho = np.zeros(8, dtype=np.float32)
+        n = fn(C.byref(p), C.byref(a), C.byref(kr), C.byref(ki), rho.ctypes.data, 8)
+        out["normalized"] = {"alpha": float(a.value), "k_re": float(kr.value), "k_im": float(ki.value), "rho": rho[:max(n, 0)].copy()}
+    return out
 
 
 class Demodulator:
@@ -162,6 +184,23 @@ class Demodulator:
         if rc < 0:
             self._check(rc, "demod_set_unpack_fold")
         return rc == 0 and on
+
+    def set_stencil_form(self, form: str = "auto") -> bool:
+        """Form of the complex stencil behind the default unpack: "auto" (normalized where the design allows it,
+        plain otherwise), "plain", "normalized", "folded" (include/demod_hip.h).  True when the context now runs
+        what was asked for."""
+        fn = getattr(self._lib, "demod_set_stencil_form", None)
+        if fn is None:      # older builds selected with DEMOD_HIP_LIBRARY: plain, or folded through the old call
+            return form in ("auto", "plain")
+        rc = fn(self._ctx, STENCIL_FORMS[form])
+        if rc < 0:
+            self._check(rc, "demod_set_stencil_form")
+        return rc == 0
+
+    @property
+    def stencil_form(self) -> str:
+        fn = getattr(self._lib, "demod_stencil_form", None)
+        return {1: "plain", 2: "folded", 3: "normalized"}.get(fn(self._ctx), "plain") if fn is not None else "plain"
 
     def set_head_mode(self, mode: int) -> None:
         """Where chunk heads are replayed: 1 inside the streaming kernel, 0 head kernels, 2 thread-per-chunk head

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMOD_ABI_VERSION 3
+#define DEMOD_ABI_VERSION 4
 
 /* Default chunk size, bytes (include/matrix.h:37-39). */
 #define DEMOD_DEFAULT_BUF_SIZE 262144u
@@ -263,19 +263,41 @@ int demod_design_query(const demod_params *p, int which, float *rows6, int max_r
  * a negative error code (as a double) with the text in demod_last_error(NULL). */
 double demod_design_magnitude_bound(const demod_params *p);
 
-/* The streaming kernel has two forms of the default (shiftOrigin) unpack in front of a complex
- * stage.  The plain one subtracts 128 from the samples: the default.  The folded one hands the
- * stencil 128 + sample and lets the stencil's constant absorb the -128: one operation per sample
- * less (+3.6 % throughput on the north-star workload), but at samples that filter to next to
- * nothing it differs from the reference by more than the reference's own builds differ from each
- * other.  It is available where that constant, -128 * sum of the taps, is
- * exactly a float (the BASELINE designs): demod_design_unpack_folded returns 1 for such an option
- * set, 0 otherwise (negative: error code, text in demod_last_error(NULL));
- * demod_set_unpack_fold(ctx, 1) -- or DEMOD_FOLD_UNPACK=1 in the environment at demod_create --
- * asks for it and returns 0 when the context's design has it, 1 when it has not (the plain form
- * stays), negative on error.  Results of the two forms differ in the last bits. */
+/* The streaming kernel has three forms of the complex stencil behind the default (shiftOrigin) unpack
+ * (-q0 with -L; DESIGN.md sections 4.1 and 5).  All compute z[k] = sum_j h[j] x[k+j] + i bias.
+ *   PLAIN       x = byte - 128, then one fused multiply-add per tap from (0, bias).
+ *   NORMALIZED  z / h[0]: X[k] + sum_{j>=1} (h[j]/h[0]) X[k+j] with X = alpha (x, x + s), s = bias / sum(h), straight
+ *               from the unpack (one packed multiply-add, exact, where PLAIN has a packed subtraction; alpha is
+ *               chosen at context creation so that its constants are floats).  The discriminator takes the
+ *               ARGUMENT of z[2n] conj(z[2n+1]), which a common positive factor does not turn: one fused
+ *               multiply-add per sample less, one rounding per filtered sample instead of one per tap.  The
+ *               taps h[j]/h[0] are floats; context creation prices what their rounding can move a full-scale
+ *               filtered sample by against what the plain form's intermediate rounding can, and offers the
+ *               form where it is not worse (the BASELINE designs: 4e-8 against 7.6e-6).
+ *   FOLDED      byte + 128-complement handed to the stencil, the -128 absorbed in its constant: at samples
+ *               that filter to next to nothing it differs from the reference by more than the reference's
+ *               own builds differ from each other; available where that constant is exactly a float.
+ * DEMOD_STENCIL_AUTO (the default) = NORMALIZED where the design allows it, PLAIN otherwise.
+ * demod_set_stencil_form returns 0, or 1 when the form asked for is not available for the context's design
+ * (the plain form runs), negative on error; demod_stencil_form says which form a context runs;
+ * demod_design_stencil_form which one AUTO gives an option set (and the two error bounds, in the
+ * reference's units of a filtered sample; host only).  demod_design_unpack_folded: 1 when FOLDED is
+ * available.  demod_set_unpack_fold(ctx, on) = demod_set_stencil_form(ctx, on ? FOLDED : AUTO).
+ * There is no environment switch: the arithmetic of a context changes only through these calls. */
+#define DEMOD_STENCIL_AUTO 0
+#define DEMOD_STENCIL_PLAIN 1
+#define DEMOD_STENCIL_FOLDED 2
+#define DEMOD_STENCIL_NORMALIZED 3
+int demod_set_stencil_form(demod_ctx *ctx, int form);
+int demod_stencil_form(const demod_ctx *ctx);
+int demod_design_stencil_form(const demod_params *p, double *normalized_error, double *plain_error);
 int demod_design_unpack_folded(const demod_params *p);
 int demod_set_unpack_fold(demod_ctx *ctx, int on);
+/* The NORMALIZED form's constants for an option set (host only; what the tests check the exactness claims on):
+ * the unpack X = alpha * (sample + 128) - (k_re, k_im) and the taps rho[j] = h[j] / h[0] (rho[0] = 1).  Returns
+ * the number of taps when the form is available for the design, 0 when it is not (the values are then what the
+ * search found, for inspection), negative on error. */
+int demod_design_normalized_constants(const demod_params *p, float *alpha, float *k_re, float *k_im, float *rho, int max_taps);
 
 /* Seamless mode (not reference behaviour; off by default): the whole stream is
  * filtered as ONE chunk, so the look-ahead stencils run across what would be

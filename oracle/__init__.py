@@ -19,6 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_SO = os.path.join(_HERE, "libdemod_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libdemod_ref.so")
+_REF_FMA_SO = os.path.join(_HERE, "_ref", "libdemod_ref_fma.so")
 
 
 class _Params(C.Structure):
@@ -59,7 +60,7 @@ def build(force: bool = False) -> None:
             os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "demod_oracle.c"))):
         subprocess.run(["make", "-C", _HERE, "libdemod_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
-    if os.path.exists("/root/reference/src/matrix.c") and (force or not os.path.exists(_REF_SO)):
+    if os.path.exists("/root/reference/src/matrix.c") and (force or not os.path.exists(_REF_SO) or not os.path.exists(_REF_FMA_SO)):
         subprocess.run(["make", "-C", _HERE, "ref"], check=True, stdout=subprocess.DEVNULL)
 
 
@@ -149,7 +150,7 @@ class _Lib:
         if self.prefix == "ref" and ((flags.mode >> 2) & 3) in (1, 2):
             # -q1 / -q2: the reference keeps static state (running offsets; a buffer sized by
             # its first call), so every stream gets a process of its own (oracle/ref_stream_main.c)
-            exe = os.path.join(os.path.dirname(self.path), "ref_stream")
+            exe = os.path.join(os.path.dirname(self.path), "ref_stream_fma" if self.path.endswith("_fma.so") else "ref_stream")
             msg = bytes(p) + np.uint64(data.size).tobytes() + data.tobytes()
             r = subprocess.run([exe], input=msg, stdout=subprocess.PIPE, check=False)
             if r.returncode != 0:
@@ -194,6 +195,23 @@ def restatement_fma() -> _Lib | None:
             subprocess.run(["make", "-C", _HERE, "libdemod_oracle_fma.so"], check=False, stdout=subprocess.DEVNULL)
         _cache["fma"] = _Lib(path, "orc") if has_fma and os.path.exists(path) else None
     return _cache["fma"]
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        return " fma " in open("/proc/cpuinfo").read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+def reference_fma() -> _Lib | None:
+    """The real reference compiled as its IS_NATIVE build comes out on an FMA machine
+    (oracle/Makefile, _ref/libdemod_ref_fma.so), or None when it has not been built (no
+    /root/reference and no prebuilt copy) or this CPU has no FMA."""
+    if "ref_fma" not in _cache:
+        build()
+        _cache["ref_fma"] = _Lib(_REF_FMA_SO, "ref") if _cpu_has_fma() and os.path.exists(_REF_FMA_SO) else None
+    return _cache["ref_fma"]
 
 
 def reference() -> _Lib | None:

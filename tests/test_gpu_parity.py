@@ -222,6 +222,23 @@ def _compare_device_result(orc, opt, iq, out, slab_chunks=256):
     return total
 
 
+# How far the REFERENCE is from itself on the same bytes -- its generic build against its IS_NATIVE (FMA) build, both
+# compiled from /root/reference, every chunk, under this criterion (tools/ref_pair_counts.py, profiles/r3_ref_pair_counts.txt):
+# outputs that need the conditioning clause / wrap outliers.  The kernel's own counts may not exceed twice the
+# reference's plus a small constant: `ok` alone would let a build pass that leans on the clause or on the wrap model
+# hundreds of times.  (Nothing may sit between the tight and the loose bound on these streams, and the exact path
+# needs neither clause nor wraps.)
+REF_PAIR = {"c2": dict(cond=0, wrap=0), "c3": dict(cond=3, wrap=6), "c5": dict(cond=1, wrap=2)}
+
+
+def _within_budget(rep, stream: str, share: float = 1.0, slack: int = 4):
+    ref = REF_PAIR[stream]
+    exact = stream == "c2"
+    assert rep.n_cond <= (0 if exact else int(np.ceil(2 * share * ref["cond"])) + slack), (stream, rep)
+    assert rep.n_wrap <= (0 if exact else int(np.ceil(2 * share * ref["wrap"])) + slack), (stream, rep)
+    assert rep.n_band == 0 and rep.n_beyond == 0, (stream, rep)
+
+
 @pytest.mark.parametrize("flags,seed", [(C2, 0xD3300D02), (C3, 0xD3300D03)], ids=["C2", "C3"])
 def test_full_size_baseline_configs(orc, flags, seed):
     """BASELINE configs 2 and 3 at their full size (2^30 samples, 8192 chunks, 5.4e8 outputs)
@@ -249,6 +266,7 @@ def test_full_size_baseline_configs(orc, flags, seed):
         rep = _compare_device_result(orc, opt, iq, out)
         print(f"\nfull size {'C3' if flags else 'C2'}: all {n_chunks} chunks compared: {rep}")
         assert rep.n == n_bytes // 4 and rep.ok, rep
+        _within_budget(rep, "c3" if flags else "c2")
         # chunk independence at scale: chunks recomputed alone, and as a batch cut out of the
         # middle of the stream, reproduce the big launch bit for bit
         rng = np.random.default_rng(seed)
@@ -299,6 +317,7 @@ def test_north_star_target_2_pow_32(orc):
         rep = compare_stream(dm, opt, got, want, data)
         print(f"\ntarget 2^32: {len(picks)} chunks compared ({sum(c >= n_chunks // 2 for c in picks)} above 4 GiB): {rep}")
         assert rep.ok, rep
+        _within_budget(rep, "c3", share=len(picks) / 8192)     # (the same design and density of events as config 3's stream)
         for c in edges + high[:24]:
             alone = d.process(iq[c * B:(c + 1) * B].clone())
             assert torch.equal(alone.view(torch.int32), out[c * Ld:(c + 1) * Ld].view(torch.int32)), c
@@ -357,6 +376,7 @@ def test_c4_shard_at_full_size(orc):
         rep = compare_stream(dm, opt, np.where(own, got, want).reshape(-1), want.reshape(-1), data)
         print(f"\nC4 shard (rank 3 of 8, 2^31 samples, cut 96 KiB into a chunk, halo): {len(picks)} chunks: {rep}")
         assert rep.ok, rep
+        _within_budget(rep, "c3", share=len(picks) / 8192)
         assert lo[0] == phase // 4 and hi[-1] == phase // 4          # both partial chunks were in the sample
 
 
@@ -379,6 +399,7 @@ def test_c5_per_gpu_share(orc):
         rep = _compare_device_result(orc, opt, iq, out, slab_chunks=per_ch // opt.buf_size)
         print(f"\nC5 share: 32 channels x 2^24 samples, every output compared: {rep}")
         assert rep.n == n_ch * per_ch // 4 and rep.ok, rep
+        _within_budget(rep, "c5")
         alone = d.process(iq[7 * per_ch:8 * per_ch].clone())
         assert torch.equal(alone.view(torch.int32), out[7 * per_ch // 4:8 * per_ch // 4].view(torch.int32))
 
@@ -445,16 +466,20 @@ def test_ill_conditioned_sample_of_a_design_whose_folded_constant_is_inexact(orc
     for k in (3, 700, 1001, 4094, 8190, 8192 + 2047, 3 * 8192 + 5555):   # complex sample index of the first of the pair
         data[2 * k:2 * k + 4] = (18 + 127, -10 + 127, 59 + 127, -36 + 127)
     with dm.Demodulator(opt) as d:
-        assert not d.set_unpack_fold(True)          # asked for, not available: the plain form stays
+        assert d.stencil_form == "normalized"       # the default for this design (round 3): the stencil divided by its first tap
         got = d.process_host(data)
+        assert not d.set_unpack_fold(True)          # asked for, not available: the plain form runs
+        assert d.stencil_form == "plain"
+        got_plain = d.process_host(data)
     want = orc.process(oracle.Flags(**opt.__dict__), data)
-    _check("planted |z| = 0.01", got, want, opt, data)
-    # beyond the criterion: within a small multiple of what the reference's other build (FMA
-    # contraction) differs by at these outputs (1.06e-4; the folded form was at 1.7e-3)
-    fma = oracle.restatement_fma()
-    if fma is not None:
-        self_diff = np.abs(fma.process(oracle.Flags(**opt.__dict__), data) - want)
-        assert float(np.abs(got - want).max()) <= 4.0 * float(self_diff.max()) + 2e-5, (np.abs(got - want).max(), self_diff.max())
+    fma = oracle.reference_fma() or oracle.restatement_fma()
+    for name, res in (("normalized", got), ("plain", got_plain)):
+        _check(f"planted |z| = 0.01, {name}", res, want, opt, data)
+        # beyond the criterion: within a small multiple of what the reference's other build (FMA
+        # contraction) differs by at these outputs (1.06e-4; the folded form was at 1.7e-3)
+        if fma is not None:
+            self_diff = np.abs(fma.process(oracle.Flags(**opt.__dict__), data) - want)
+            assert float(np.abs(res - want).max()) <= 4.0 * float(self_diff.max()) + 2e-5, (name, np.abs(res - want).max(), self_diff.max())
 
 
 @pytest.mark.parametrize("kw", [C3, dict(sample_rate=96000.0, lowpass_in=12500.0, lowpass_out=6500.0),
@@ -470,6 +495,16 @@ def test_adversarial_small_filtered_samples(orc, kw):
     reaches 1e-2 once in 1e10 samples) and planted at both alignments among random neighbours.
     The discriminator value there is error / |z| radians off; the criterion's clause, pinned to
     the reference's own self-difference, has to hold."""
+    opt, data = adversarial_case(kw)
+    with dm.Demodulator(opt) as d:
+        got = d.process_host(data)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    rep = _check(f"adversarial {kw}", got, want, opt, data)
+    print(f"adversarial {kw}: {rep}")
+
+
+def adversarial_case(kw, seed: int = 5):
+    """(options, bytes): the 1,024 sample groups with the smallest filtered |z| of a design, planted among random bytes."""
     opt = dm.Options(buf_size=65536, **kw)
     din = dm.design(opt, "in")
     h = np.asarray(din["taps"], dtype=np.float64)
@@ -489,7 +524,7 @@ def test_adversarial_small_filtered_samples(orc, kw):
         flat = np.argpartition(np.abs(lane + bias), 32, axis=None)[:32]
         best.append([np.unravel_index(int(i), lane.shape) for i in flat])
     groups = [(re, im) for re in best[0] for im in best[1]]          # 1,024 groups of T complex samples
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed)
     n_chunks = 4
     data = rng.integers(0, 256, n_chunks * opt.buf_size, dtype=np.uint8)
     slots = rng.permutation(np.arange(40, n_chunks * opt.buf_size // 2 - 40, 7))[:len(groups)]   # odd stride: both alignments
@@ -497,11 +532,7 @@ def test_adversarial_small_filtered_samples(orc, kw):
         for j in range(T):
             data[2 * (k + j)] = to_byte(int(re[j]))
             data[2 * (k + j) + 1] = to_byte(int(im[j]))
-    with dm.Demodulator(opt) as d:
-        got = d.process_host(data)
-    want = orc.process(oracle.Flags(**opt.__dict__), data)
-    rep = _check(f"adversarial {kw}", got, want, opt, data)
-    print(f"adversarial {kw}: {rep}")
+    return opt, data
 
 
 def test_nothing_is_written_outside_the_result(orc):
@@ -537,27 +568,48 @@ def test_nothing_is_written_outside_the_result(orc):
                     assert torch.equal(buf[guard:guard + n_out], d.process(iq)), (kw, B, fmt, n_bytes)
 
 
-def test_folded_unpack_is_an_option_not_the_default(orc):
-    """The streaming kernel subtracts 128 from the samples by default; the folded form (the
-    stencil's constant absorbs it: 3.6 % faster, but outside the criterion at samples searched
-    for |z| ~ 0, tools/adversarial_sweep.py) has to be asked for, is offered where its constant
-    is exact (the BASELINE designs) and is inside the criterion on an ordinary stream."""
-    import torch
+def test_stencil_forms_and_what_a_degraded_one_looks_like(orc):
+    """The complex stencil behind the default unpack has three forms (include/demod_hip.h).  The default is the one
+    divided by its first tap where build_plan allows it (BASELINE config 3 / the target), else the plain one; both
+    hold the criterion on the design's searched worst-case inputs.  The folded form is an option only -- and it is
+    this suite's proof that the criterion has teeth: on the same inputs it leaves the criterion (more outputs
+    between the bounds than the 1e-5 share allows), where the reference's own FMA build stays inside it."""
     opt = dm.Options(**C3)
-    data = oracle.synth_bytes(0xF01D + 1, 0, 8 * opt.buf_size)
+    assert dm.design(opt)["stencil_form"] == "normalized"
+    data = oracle.synth_bytes(0xF01D, 0, 3 * opt.buf_size)
     want = orc.process(oracle.Flags(**opt.__dict__), data)
-    iq = torch.from_numpy(data).cuda()
+    res = {}
     with dm.Demodulator(opt) as d:
-        plain = d.process(iq).cpu().numpy()
-        assert d.set_unpack_fold(True)
-        folded = d.process(iq).cpu().numpy()
-        assert not d.set_unpack_fold(False)
-        assert np.array_equal(d.process(iq).cpu().numpy().view(np.uint32), plain.view(np.uint32))
-    _check("plain", plain, want, opt, data)
-    _check("folded", folded, want, opt, data)
-    assert not np.array_equal(plain.view(np.uint32), folded.view(np.uint32))      # another rounding, the same result to 1e-5
-    assert float(np.abs(plain - folded).max()) < 1e-3
-
+        assert d.stencil_form == "normalized"
+        for form in ("normalized", "plain", "folded", "auto"):
+            assert d.set_stencil_form(form)
+            assert d.stencil_form == ("normalized" if form == "auto" else form)
+            res[form] = d.process_host(data)
+            _check(form, res[form], want, opt, data)
+    assert np.array_equal(res["auto"].view(np.uint32), res["normalized"].view(np.uint32))
+    for other in ("plain", "folded"):           # another rounding, the same result to 1e-5
+        assert not np.array_equal(res[other].view(np.uint32), res["normalized"].view(np.uint32))
+        assert float(np.abs(res[other] - res["normalized"]).max()) < 1e-3
+    with dm.Demodulator(dm.Options(mode=0x18, **C3)) as d:      # -q2: plain, whatever is asked for
+        assert d.stencil_form == "plain" and not d.set_stencil_form("normalized") and not d.set_stencil_form("folded")
+        assert d.stencil_form == "plain"
+    with dm.Demodulator(dm.Options()) as d:                     # no complex stage
+        assert d.stencil_form == "plain"
+    # the searched inputs of a design whose folded constant is exact (so that the form is available at all)
+    kw = dict(lowpass_in=12500.0, in_degree=4)
+    opt, data = adversarial_case(kw)
+    want = orc.process(oracle.Flags(**opt.__dict__), data)
+    reports = {}
+    with dm.Demodulator(opt) as d:
+        for form in ("normalized", "plain", "folded"):
+            assert d.set_stencil_form(form), form
+            reports[form] = compare_stream(dm, opt, d.process_host(data), want, data)
+            print(f"adversarial {kw} {form}: {reports[form]}")
+    assert reports["normalized"].ok and reports["plain"].ok
+    assert not reports["folded"].ok and reports["folded"].n_band > 2, reports["folded"]
+    fma = oracle.reference_fma() or oracle.restatement_fma()
+    if fma is not None:
+        assert compare_stream(dm, opt, fma.process(oracle.Flags(**opt.__dict__), data), want, data).ok
 
 def test_random_call_patterns(orc):
     """Seeded sweep over HOW a stream reaches the path rather than over its options: one stream,

@@ -193,6 +193,64 @@ def test_folded_unpack_is_offered_only_where_its_constant_is_exact():
     assert 10 < n_exact < 190
 
 
+def test_normalized_stencil_constants_are_exact_where_the_form_is_offered():
+    """The streaming kernel's default for -q0 with -L (round 3): the complex stencil divided by its first tap, its
+    constant riding on the unpack X = alpha * (sample + 128) - (k_re, k_im) (plan.cpp, price_normalised_stencil).
+    What the kernel relies on, checked in exact rational arithmetic for every design the form is offered for:
+      * alpha has 16 significant bits and k_re = 128 alpha exactly: the real lane is alpha * x to the bit;
+      * alpha * U - k_im is a float for EVERY byte value U (no rounding in the unpack), and below 2^8;
+      * the bias this applies, h0 (1 + sum rho) (128 - k_im / alpha), is the design's to within half an ulp of it;
+      * the taps h0 rho_j are the design's to within what build_plan reports (normalized_error), which is not above
+        what the plain form's intermediate rounding can do (plain_error);
+    and the form is never offered for -q2 or without a complex stage.  BASELINE config 3 / the target has it."""
+    from fractions import Fraction as F
+
+    def f32(x):
+        return F(float(np.float32(float(x))))
+
+    def check(opt):
+        d = dm.design(opt)
+        din = dm.design(opt, "in")
+        c = d["normalized"]
+        alpha, k_re, k_im = F(c["alpha"]), F(c["k_re"]), F(c["k_im"])
+        rho = [F(float(r)) for r in c["rho"]]
+        h = [F(float(np.float32(t))) for t in din["taps"]]
+        bias = F(float(np.float32(din["bias_im"])))
+        assert (alpha * 2 ** 15).denominator == 1 and 1 <= alpha < F(3, 2)
+        assert k_re == 128 * alpha and 128 <= k_im < 256
+        for U in range(256):
+            x = alpha * U - k_im
+            assert f32(x) == x and abs(x) < 256, (opt, U)
+            assert f32(alpha * U - k_re) == alpha * (U - 128)
+        assert rho[0] == 1 and len(rho) == len(h)
+        applied = h[0] * sum(rho) * (128 - k_im / alpha)
+        ulp = F(2) ** (int(np.floor(np.log2(abs(float(bias))))) - 23)
+        assert abs(applied - bias) <= ulp / 2, (opt, float(applied - bias))
+        taps_err = sum(abs(h[0] * r - hj) for r, hj in zip(rho, h)) * 128
+        # (normalized_error as reported includes the bias term bounded above)
+        assert float(taps_err) <= d["normalized_error"] + 1e-12 and d["normalized_error"] <= d["plain_error"] + float(ulp / 2), opt
+
+    L = dict(lowpass_in=12500.0, lowpass_out=6500.0)
+    assert dm.design(dm.Options(**L))["stencil_form"] == "normalized"
+    check(dm.Options(**L))
+    assert dm.design(dm.Options())["stencil_form"] == "plain"                    # no complex stage
+    assert dm.design(dm.Options(mode=0x18, **L))["stencil_form"] == "plain"      # -q2: highpass taps, plain
+    assert dm.design(dm.Options(mode=0x1C, **L))["stencil_form"] == "plain"      # -q3: another unpack
+    rng = np.random.default_rng(8)
+    offered = 0
+    for _ in range(150):
+        opt = dm.Options(sample_rate=float(rng.choice([96000.0, 125000.0, 192000.0, 250000.0])), lowpass_in=float(rng.integers(3000, 30000)),
+                         in_degree=int(rng.integers(1, 17)), mode=0x10 | int(rng.integers(0, 4)))
+        try:
+            d = dm.design(opt)
+        except dm.DemodError:
+            continue
+        if d["stencil_form"] == "normalized":
+            offered += 1
+            check(opt)
+    assert offered > 50
+
+
 def test_every_accepted_design_is_proven_finite():
     """The reference maps a NaN discriminator value to 0 (/root/reference/src/matrix.c:174).
     NaN needs non-finite arithmetic; build_plan bounds every intermediate of the reference's

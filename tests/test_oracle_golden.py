@@ -163,6 +163,17 @@ def test_reference_self_difference_pins_the_conditioning_clause(orc):
     fma = oracle.restatement_fma()
     if fma is None:
         pytest.skip("no FMA on this CPU")
+    # The pair that pins the clause is the REFERENCE ITSELF: /root/reference/src/*.c compiled twice by
+    # oracle/Makefile, generic (_ref/libdemod_ref.so) and as cmake_build.sh's IS_NATIVE build comes out on an
+    # FMA machine (_ref/libdemod_ref_fma.so).  Where those objects are absent (no /root/reference and no
+    # prebuilt copy) the restatement's two builds stand in -- bit-identical to the reference's, asserted below
+    # and over the whole BASELINE streams by test_restatement_equals_reference_on_every_chunk_of_the_baseline_streams.
+    ref, ref_fma = oracle.reference(), oracle.reference_fma()
+    pinned_by_reference = ref is not None and ref_fma is not None
+    gen = ref if pinned_by_reference else orc
+    nat = ref_fma if pinned_by_reference else fma
+    threads = {} if pinned_by_reference else dict(threads=4)    # (the reference's functions run one stream per call)
+    print(f"clause pinned by: {'the reference (oracle/_ref, generic and FMA builds)' if pinned_by_reference else 'the restatement (no oracle/_ref)'}")
     worst = 0.0
     # -- BASELINE config 3, the chunks named above ------------------------------------------
     opt = dm.Options(lowpass_in=12500.0, lowpass_out=6500.0)
@@ -173,7 +184,9 @@ def test_reference_self_difference_pins_the_conditioning_clause(orc):
     beyond, wraps = 0, 0
     for c in (2819, 4174, 5812, 1046, 6468, 7696):
         data = oracle.synth_bytes(0xD3300D03, c * B, B)
-        a, b = orc.process(fl, data), fma.process(fl, data)
+        a, b = gen.process(fl, data), nat.process(fl, data)
+        if pinned_by_reference:      # the stand-ins are the same functions, to the bit, in both builds
+            assert np.array_equal(bits(a), bits(orc.process(fl, data))) and np.array_equal(bits(b), bits(fma.process(fl, data))), c
         plain = parity.compare(b, a, taps, True, None)
         full = parity.compare_stream(dm, opt, b, a, data)
         assert full.ok, (c, full)
@@ -196,7 +209,7 @@ def test_reference_self_difference_pins_the_conditioning_clause(orc):
         opt = dm.Options(**kw)
         fl = oracle.Flags(**opt.__dict__)
         data = rng.integers(0, 256, 16 << 20, dtype=np.uint8)
-        a, b = orc.process(fl, data, threads=4), fma.process(fl, data, threads=4)
+        a, b = gen.process(fl, data, **threads), nat.process(fl, data, **threads)
         plain_failures += not parity.compare(b, a, dm.design(opt)["taps"], True, None).ok
         full = parity.compare_stream(dm, opt, b, a, data)
         assert full.ok, (kw, full)
@@ -233,3 +246,112 @@ def test_q2_reference_differs_from_itself_within_the_conditioning_clause(orc):
         plain_failures += not compare(b, a, taps, True, None).ok
         assert compare_stream(dm, opt, b, a, data).ok, opt
     assert plain_failures >= 1      # the clause is needed: without it the reference fails against itself
+
+
+# ---------------------------------------------------------------------------
+# the restatement IS the reference on the whole BASELINE streams
+# ---------------------------------------------------------------------------
+def _slab_equal(args):
+    """Child process: chunks [first, first + count) of a BASELINE stream through the compiled reference and
+    through the restatement; number of outputs whose bits differ (and outputs compared)."""
+    flags, seed, first, count, fma_too = args
+    fl = oracle.Flags(**flags)
+    B = fl.buf_size
+    orc = oracle.restatement()
+    data = orc.synth_bytes(seed, first * B, count * B)
+    want = oracle.reference().process(fl, data)
+    bad = int((bits(orc.process(fl, data)) != bits(want)).sum())
+    if fma_too:
+        bad += int((bits(oracle.restatement_fma().process(fl, data)) != bits(oracle.reference_fma().process(fl, data))).sum())
+    return bad, want.size
+
+
+@pytest.mark.parametrize("name,flags,seed", [("C2", dict(), 0xD3300D02),
+                                             ("C3", dict(lowpass_in=12500.0, lowpass_out=6500.0), 0xD3300D03)])
+def test_restatement_equals_reference_on_every_chunk_of_the_baseline_streams(name, flags, seed):
+    """The full-size GPU tests compare with the restatement (the reference's sources do not travel to the GPU
+    box); this closes the chain at full size: ALL 8192 chunks of BASELINE config 2's and config 3's synthetic
+    streams through the reference's own functions (oracle/_ref, compiled from /root/reference) and through the
+    restatement, bit for bit -- 5.4e8 outputs each, in slabs handed to child processes.  Every eighth slab also
+    runs the two FMA builds against each other (the pair behind the conditioning clause)."""
+    from multiprocessing import get_context
+    if oracle.reference() is None:
+        pytest.skip("oracle/_ref not present (no /root/reference on this machine)")
+    have_fma = oracle.reference_fma() is not None and oracle.restatement_fma() is not None
+    n_chunks, slab = (2 << 30) // 262144, 64
+    jobs = [(flags, seed, first, slab, have_fma and (first // slab) % 8 == 0) for first in range(0, n_chunks, slab)]
+    import os
+    with get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+        results = pool.map(_slab_equal, jobs)
+    assert sum(n for _, n in results) == (2 << 30) // 4
+    assert sum(b for b, _ in results) == 0, f"{name}: restatement and reference differ"
+
+
+# ---------------------------------------------------------------------------
+# tests/parity.py itself: planted errors must fail
+# ---------------------------------------------------------------------------
+def test_parity_criterion_rejects_planted_errors(orc):
+    """tests/parity.py is model code shared by every parity test: a bug there loosens everything at once.
+    A correct result passes; each of these planted errors must NOT:
+      * a +-2 pi h0 difference (the shape of a wrap outlier) at an output whose discriminator argument is far
+        from the negative real axis;
+      * 3e-4 of error at an output of ordinary size (filtered samples hundreds of units long: the clause
+        allows nothing there);
+      * a systematic 1e-4 offset on 1e-4 of the outputs (inside the loose bound, but ten times the share the
+        criterion lets sit between its bounds);
+      * in the exact path: 5e-6 on one output, and a flipped +-pi;
+      * NaN anywhere."""
+    import demodulator_amd as dm
+    import parity
+    rng = np.random.default_rng(12)
+    opt = dm.Options(lowpass_in=12500.0, lowpass_out=6500.0)
+    fl = oracle.Flags(**opt.__dict__)
+    B = opt.buf_size
+    data = oracle.synth_bytes(0xD3300D03, 0, 4 * B)
+    want = orc.process(fl, data)
+    taps = dm.design(opt)["taps"]
+    assert parity.compare_stream(dm, opt, want.copy(), want, data).ok
+    cond = parity.conditioning(dm, opt, data)
+    interior = np.nonzero((cond.cond < 1e-6) & ~cond.near_axis & (np.arange(want.size) % (B // 4) >= 8))[0]
+    assert interior.size > want.size // 2            # ordinary outputs: no allowance, nowhere near the branch cut
+
+    def planted(change, use_model=True):
+        got = want.copy()
+        change(got)
+        return parity.compare_stream(dm, opt, got, want, data) if use_model else parity.compare(got, want, taps, True, None)
+
+    i = int(interior[1234])
+    rep = planted(lambda g: g.__setitem__(i, g[i] + np.float32(2 * np.pi * taps[0])))
+    assert not rep.ok and rep.n_beyond == 1 and rep.n_wrap == 0, rep          # wrap-shaped, but not at the axis
+    rep = planted(lambda g: g.__setitem__(i, g[i] - np.float32(2 * np.pi * (taps[0] + taps[1]))))
+    assert not rep.ok and rep.n_wrap == 0, rep
+    rep = planted(lambda g: g.__setitem__(i, g[i] + np.float32(3e-4) * max(1.0, abs(float(g[i])))))
+    assert not rep.ok and rep.n_beyond == 1, rep
+    some = interior[rng.choice(interior.size, want.size // 10000, replace=False)]
+
+    def offset(g):
+        g[some] += np.float32(6e-5) * np.maximum(1.0, np.abs(g[some]))
+    rep = planted(offset)
+    assert not rep.ok and rep.n_beyond == 0 and rep.n_band >= some.size - 2, rep   # inside the loose bound, too many of them
+    rep = planted(lambda g: g.__setitem__(i, np.float32(np.nan)))
+    assert not rep.ok, rep
+    # without the input bytes the wrap allowance is capped: a systematic sign error cannot pass as "wraps"
+    many = interior[:64]
+    rep = planted(lambda g: g.__setitem__(many, g[many] + np.float32(2 * np.pi * taps[0])), use_model=False)
+    assert not rep.ok, rep
+    # a head output gets no allowance even where the model would give one elsewhere
+    rep = planted(lambda g: g.__setitem__(3, g[3] + np.float32(3e-4) * max(1.0, abs(float(g[3])))))
+    assert not rep.ok, rep
+
+    # exact path (no complex stage): 4e-6 absolute on every output, +-pi signs exact
+    opt2 = dm.Options()
+    fl2 = oracle.Flags(**opt2.__dict__)
+    quads = np.tile(np.array([127, 130, 127, 120], dtype=np.uint8), B // 4)     # every discriminator value is +pi
+    d2 = np.concatenate([oracle.synth_bytes(0xD3300D02, 0, B), quads])
+    w2 = orc.process(fl2, d2)
+    t2 = dm.design(opt2)["taps"]
+    assert parity.compare_stream(dm, opt2, w2.copy(), w2, d2).ok
+    g2 = w2.copy(); g2[1000] += np.float32(5e-6)
+    assert not parity.compare_stream(dm, opt2, g2, w2, d2).ok
+    g2 = w2.copy(); g2[B // 4 + 100] -= np.float32(2 * np.pi * t2[0])           # -pi where the reference has +pi
+    assert not parity.compare_stream(dm, opt2, g2, w2, d2).ok
