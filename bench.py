@@ -202,12 +202,23 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     dt = time.perf_counter() - t0
     kms, launches = d.kernel_ms()
     dispatches = max(1, d.last_call_launches)
+    # what the look-ahead exchange costs a step, measured on its own AFTER the timed region (the K steps above are
+    # not instrumented): K exchanges, each waited for -- issue, transport and completion, an upper bound on what a
+    # step pays, since there the exchange overlaps the previous step's kernel
+    halo_us = None
+    if me.needs_halo or me.sends_halo:
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(steps):
+            exchange()
+            torch.cuda.synchronize()
+        halo_us = (time.perf_counter() - th) / steps * 1e6
     checksum = float(out[1000003:: max(1, out.numel() // 4099)].double().abs().sum().item())
     d.close()
     del iq, out
     torch.cuda.empty_cache()
     return dict(dt=dt, kernel_ms=kms, launches=launches, n_bytes=n_bytes, opt=opt, checksum=checksum,
-                phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches)
+                phase=phase, chunk=B, exchanged=bool(me.needs_halo or me.sends_halo), dispatches=dispatches, halo_us=halo_us)
 
 
 def _free_port() -> int:
@@ -251,6 +262,84 @@ def self_launch(n: int) -> int:
     return worst
 
 
+def single_process(args) -> int:
+    """`--single-process`: the same workload and the same line, with ONE process driving every device through
+    demod_multi_* (demodulator_amd/csrc/multi.cpp) -- the C-level multi-GPU entry and its native grouped
+    ncclSend/ncclRecv get a number of their own beside torch.distributed's.  A step = exchange + one enqueue per
+    device; the K steps are bracketed by a synchronize of every device's stream (there is one process: no barrier)."""
+    import torch
+
+    import demodulator_amd as dm
+
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have == 0:
+        raise SystemExit("bench.py needs an MI355X: the demodulation path has no CPU fallback")
+    distinct = have >= n
+    devices = list(range(n)) if distinct else [i % have for i in range(n)]   # fewer devices than shards: a rehearsal, said so in the line
+    wl = WORKLOADS[args.workload]
+    n_bytes = 2 << wl["log2_samples"]
+    opt = dm.Options(**wl["flags"])
+    phase = 0 if (args.aligned or n == 1) else PHASE_BYTES
+    m = dm.MultiDemodulator(opt, devices)
+    shards = m.plan(n_bytes * n, phase)
+    ins, outs = [], []
+    for i, dev in enumerate(devices):
+        with torch.cuda.device(dev):
+            iq = torch.empty(n_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
+            with dm.Demodulator(opt, device=dev) as d:
+                d.synth_fill(iq, shards[i].start, wl["seed"])
+                torch.cuda.synchronize()
+            ins.append(iq)
+            outs.append(torch.empty(n_bytes // 4, dtype=torch.float32, device=f"cuda:{dev}"))
+    m.enable_timing(True)
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < args.prewarm_ms:
+        m.process(ins, outs, shards)
+        m.synchronize()
+    for _ in range(args.warmup):
+        m.process(ins, outs, shards)
+    m.synchronize()
+    for i in range(n):
+        m.kernel_ms(i)          # drop warm-up timings
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.process(ins, outs, shards)
+    m.synchronize()
+    dt = time.perf_counter() - t0
+    per_dev = [m.kernel_ms(i) for i in range(n)]
+    transport = m.halo_transport
+    checksum = float(outs[0][1000003:: max(1, outs[0].numel() // 4099)].double().abs().sum().item())
+    m.close()
+    samples_per_gpu = n_bytes // 2
+    kern = [ms / max(1, disp) for ms, _, disp in per_dev]
+    algo = ALGO_BYTES_PER_SAMPLE * samples_per_gpu // max(1, per_dev[0][2])
+    achieved = algo / (kern[0] * 1e-3) if kern[0] > 0 else None
+    line = {
+        "metric": "IQ Msamples/sec (input) end-to-end demod+filter",
+        "value": round(samples_per_gpu * n * args.steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (counter-based splitmix64 uint8 IQ, generated on device)",
+        "halo_exchange": {"rccl": "rccl send/recv (grouped, one thread)", "peer-copy": "hipMemcpyPeerAsync (RCCL unavailable or refused the device list)",
+                          "none": "none (chunk-aligned cuts)" if n > 1 else "none (1 GPU)"}.get(transport, transport),
+        "config": {"workload": f"{args.workload}: {wl['desc']}", "samples_per_gpu": samples_per_gpu, "chunk_bytes": opt.buf_size,
+                   "sharding": "1 GPU" if n == 1 else f"{n} contiguous shards, " + (f"cuts {phase} B into a chunk, 64-byte look-ahead per step" if phase else "chunk-aligned cuts, no exchange")},
+        "multi": {"mode": "one process, demod_multi_* (C ABI, multi.cpp)", "halo_transport": transport,
+                  "devices": devices, "devices_distinct": distinct,
+                  "kernel_ms_per_dispatch_min": round(min(kern), 4), "kernel_ms_per_dispatch_max": round(max(kern), 4)},
+        "roofline": {"bound": "hbm", "kernel": "demod_rows (fused unpack + complex stencil + discriminator/atan2 + real stencil), device 0",
+                     "achieved": round(achieved / 1e9, 1) if achieved else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK, 4) if achieved else None, "algorithmic_bytes_per_launch": algo,
+                     "kernel_ms": round(kern[0], 4), "launches_per_step": per_dev[0][2], "traffic": None},
+        "checksum": checksum,
+    }
+    if not distinct:
+        line["multi"]["note"] = f"REHEARSAL: {have} device(s) for {n} shards -- contexts share devices, not a scaling number"
+    print(json.dumps(line))
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,8 +355,14 @@ def main() -> int:
     ap.add_argument("--probe-timeout", type=float, default=240.0,
                     help="seconds the point-to-point health check may take before it is killed (on a fresh box the "
                          "probe's processes page in torch and the 570 MB librccl before they start)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from THIS process through the C ABI's demod_multi_* (multi.cpp: one context and "
+                         "stream per device, the look-ahead of every cut by grouped ncclSend/ncclRecv from one thread) instead of one "
+                         "process per GPU")
     args = ap.parse_args()
 
+    if args.single_process:
+        return single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)   # before torch is imported: the parent never touches the GPU
 
@@ -348,9 +443,16 @@ def main() -> int:
     r = run_workload(dm, torch, dist, args.workload, args.steps, args.warmup, rank, world, args.aligned,
                      args.segment_rows, args.prewarm_ms, data_group)
     dt = r["dt"]
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # every rank's own numbers, for the line: step time, kernel time per dispatch, what an exchange costs
+        mine = torch.tensor([r["dt"] / args.steps * 1e3, r["kernel_ms"] / max(1, r["dispatches"]),
+                             -1.0 if r["halo_us"] is None else r["halo_us"]], dtype=torch.float64)
+        every = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(v) for v in e] for e in every]
         dt = float(t.item())
 
     samples_per_gpu = r["n_bytes"] // 2
@@ -384,6 +486,22 @@ def main() -> int:
                           f"{'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} send/recv per step")),
         },
     }
+    if world > 1:
+        # what the first real multi-GPU run has to tell: how many ranks the RCCL group really has (0: none was made),
+        # how far the ranks' step and kernel times spread, what the 64-byte exchange costs
+        steps_ms = [p[0] for p in per_rank]
+        kern_ms = [p[1] for p in per_rank]
+        halos = [p[2] for p in per_rank if p[2] >= 0]
+        line["multi"] = {
+            "mode": "one process per GPU (torch.distributed)",
+            "rccl_ranks": int(dist.get_world_size(group=data_group)) if data_group is not None else 0,
+            "control_ranks": int(dist.get_world_size()),
+            "devices_visible_to_rank0": int(torch.cuda.device_count()),
+            "ms_per_step_min": round(min(steps_ms), 4), "ms_per_step_max": round(max(steps_ms), 4),
+            "kernel_ms_per_dispatch_min": round(min(kern_ms), 4), "kernel_ms_per_dispatch_max": round(max(kern_ms), 4),
+            "halo_us_per_step": round(max(halos), 1) if halos else None,
+            "halo_us_per_step_note": "exchange alone, waited for, after the timed region (upper bound; max over ranks)" if halos else "no exchange",
+        }
     if rank == 0:
         # one step dispatches demod_rows once per 2 GiB piece of input, back to back;
         # the library's HIP events bracket all of them: per-dispatch figures below

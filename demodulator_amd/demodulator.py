@@ -454,6 +454,18 @@ class MultiDemodulator:
     def halo_transport(self) -> str:
         return self._lib.demod_multi_halo_transport(self._m).decode()
 
+    def enable_timing(self, on: bool = True) -> None:
+        """HIP-event timing of the streaming kernel on every device's context (demod_enable_timing)."""
+        for i in range(len(self.devices)):
+            self._lib.demod_enable_timing(self._lib.demod_multi_context(self._m, i), 1 if on else 0)
+
+    def kernel_ms(self, i: int):
+        """(average fused-kernel milliseconds per call, calls, dispatches of the last call) of device i's context."""
+        ctx = self._lib.demod_multi_context(self._m, i)
+        n = C.c_int(0)
+        ms = self._lib.demod_kernel_ms(ctx, C.byref(n))
+        return float(ms), int(n.value), int(self._lib.demod_last_call_launches(ctx))
+
     def close(self) -> None:
         if self._m.value:
             self._lib.demod_multi_destroy(self._m)

@@ -12,7 +12,8 @@ shader cycles per wave64 instruction per SIMD at 8 wavefronts per SIMD).  SQ_INS
 (count per segment) x (segments per dispatch = rows / 4).
 
 Phases are recognised from the mnemonics (the kernel has one use for each):
-  unpack     v_and 0x7f7f7f7f, v_add_u32 0x1010101, v_bitop3 0x78, v_cvt_f32_ubyteN, v_pk_add_f32
+  unpack     v_and 0x7f7f7f7f, v_add_u32 0x1010101, v_bitop3 0x78, v_cvt_f32_ubyteN, v_pk_add_f32 (plain) or
+             v_pk_fma_f32 v, v, s (normalised: alpha * byte - k)
   stencil_in v_pk_fma_f32 with an SGPR-pair first operand (taps in scalar registers)
   discrim    the inline-asm v_pk_mul_f32 / v_pk_fma_f32 with op_sel (discriminator_argument)
   atan2      v_sub |a|,|b|, v_ashrrev 31, v_bitop3 0xca, v_rcp, v_mul_legacy, polynomial pk ops, v_and pi masks
@@ -60,8 +61,13 @@ def phase_of(op: str, line: str, in_asm: bool) -> str:
     if in_asm and op.startswith("v_pk_"):
         return "discrim"
     if op.startswith("v_pk_fma_f32"):
-        # taps live in scalar registers: the complex stencil's first operand is an SGPR pair
-        return "stencil_in" if re.search(r"v_pk_fma_f32 v\[\d+:\d+\], s\[", line) else "atan2"
+        # taps live in scalar registers: the complex stencil's first source is an SGPR pair; the normalised form's
+        # unpack alpha * byte - k has its scalar (alpha) as the second source; the polynomial's as the third
+        if re.search(r"v_pk_fma_f32 v\[\d+:\d+\], s\[", line):
+            return "stencil_in"
+        if re.search(r"v_pk_fma_f32 v\[\d+:\d+\], v\[\d+:\d+\], s\[", line):
+            return "unpack"
+        return "atan2"
     if op.startswith("v_pk_mul_f32"):
         return "atan2"
     if op.startswith(("v_rcp_f32", "v_mul_legacy_f32", "v_ashrrev_i32", "v_sub_f32")) or "bitop3:0xca" in line:
