@@ -26,7 +26,7 @@ EXPORTS = (
     "demod_copy_to_host", "demod_synchronize", "demod_get_sos", "demod_get_taps",
     "demod_get_head_outputs", "demod_design_query", "demod_set_seamless", "demod_set_output_format",
     "demod_output_bytes", "demod_set_segment_rows", "demod_set_piece_rows", "demod_synth_fill",
-    "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_kernel_ms", "demod_last_call_launches",
+    "demod_selftest_atan2", "demod_selftest_lane_shift", "demod_selftest_q1_offsets", "demod_kernel_ms", "demod_last_call_launches",
     "demod_enable_timing", "demod_last_error_code", "demod_design_magnitude_bound", "demod_design_unpack_folded", "demod_set_unpack_fold", "demod_set_head_mode",
     "demod_set_stencil_form", "demod_stencil_form", "demod_design_stencil_form", "demod_design_normalized_constants",
     "demod_stream_depth", "demod_ring_slots_for", "demod_ring_create", "demod_ring_destroy", "demod_ring_input",
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
         "demod_selftest_atan2": (i32, [vp, vp, vp, vp, u32]),
         "demod_selftest_lane_shift": (i32, [vp, vp, C.c_float, vp]),
         "demod_kernel_ms": (C.c_double, [vp, C.POINTER(i32)]),
+        "demod_selftest_q1_offsets": (i32, [vp, vp, C.c_uint64, vp]),
         "demod_last_call_launches": (i32, [vp]),
         "demod_enable_timing": (None, [vp, i32]),
         "demod_last_error_code": (i32, [vp]),

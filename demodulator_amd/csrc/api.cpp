@@ -352,6 +352,7 @@ static int run_offsets(demod_ctx *ctx, const uint8_t *d_in, uint64_t n_bytes, ui
     o.tail_bytes = (uint32_t) (n_bytes - o.n_chunks * B);
     o.stride = (uint32_t) (B / 4);
     o.warm = pl.q1_warm;
+    o.retry = pl.q1_retry;
     // Every thread repeats the run-in before what it writes, so more threads shorten the chain
     // only down to the run-in's own length, and they multiply the work -- 16-byte requests to 64
     // different cache lines per load instruction, paid for in the CU's address unit.  A budget
@@ -830,6 +831,28 @@ int demod_selftest_atan2(demod_ctx *ctx, const float *h_y, const float *h_x, flo
     }
     (void) hipFree(d);
     return rc;
+}
+
+int demod_selftest_q1_offsets(demod_ctx *ctx, float *h_pairs, uint64_t n_pairs, float *h_state2) {
+    if (!ctx) return DEMOD_E_INVAL;
+    if (ctx->plan.conditioning != kCorrectIq) {
+        ctx->fail(DEMOD_E_INVAL, "not a -q1 context");
+        return DEMOD_E_INVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (h_pairs && n_pairs) {
+        if (!ctx->q1_table || n_pairs > ctx->q1_pairs) {
+            ctx->fail(DEMOD_E_INVAL, "more offsets asked for than the last call's table holds");
+            return DEMOD_E_INVAL;
+        }
+        HIP_TRY(ctx, hipMemcpy(h_pairs, ctx->q1_table, n_pairs * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (h_state2) {
+        h_state2[0] = h_state2[1] = 0.f;   // no call yet: the reference's static offsets start at zero
+        if (ctx->q1_carry) HIP_TRY(ctx, hipMemcpy(h_state2, ctx->q1_carry + 2 * ctx->q1_flip, 2 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return DEMOD_OK;
 }
 
 int demod_selftest_lane_shift(demod_ctx *ctx, const float *h_in64, float halo, float *h_out64) {

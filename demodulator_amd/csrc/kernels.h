@@ -110,7 +110,8 @@ struct OffsetLaunch {
     uint64_t n_chunks;         // full chunks
     uint32_t tail_bytes;       // trailing short chunk (multiple of 4), 0 = none
     uint32_t stride;           // table pairs per chunk = chunk_bytes / 4
-    uint32_t warm;             // iterations of run-in before a chunk (Plan::q1_warm)
+    uint32_t warm;             // iterations of the first run-in before a piece (Plan::q1_warm) ...
+    uint32_t retry;            // ... and how much further back the second one starts (Plan::q1_retry); then twice as far each time
     uint32_t parts;            // threads that share one chunk (>= 1) ...
     uint32_t group;            // ... or chunks one thread walks through (>= 1; one of the two is 1)
     float esr;

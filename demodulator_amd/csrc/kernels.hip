@@ -1513,15 +1513,26 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
 //     off += ((byte[t] - off) + (byte[K-1-t] - off)) * esr        (re and im lanes alike),
 // and its static offsets carry on from chunk to chunk: a float recurrence over the whole stream,
 // every step rounded, so it cannot be re-associated.  It contracts, though -- a start value is
-// forgotten at the rate (1 - 2 esr) per iteration -- so a thread replays the literal operations
-// over the `warm` iterations BEFORE the piece of the stream it writes (from the call's
-// carried-in state when they reach that far back, from an arbitrary value otherwise: by then
-// its influence has shrunk below 2^-26 twice over and the float sequence has locked onto the
-// reference's), then through its piece, writing the offsets every iteration starts from.
+// forgotten at the rate (1 - 2 esr) per iteration -- and the rounded step is monotone in the offset
+// (a larger offset never comes out smaller: each of its roundings is monotone, and for offsets a
+// whole ulp apart the exact step's (1 - 2 esr) ulp dwarfs what the roundings of the small terms can
+// undo).  So a thread replays the literal operations over a RUN-IN before the piece of the stream
+// it writes, on a BRACKET: two copies of the state, started at 0 and at 255, between which the
+// reference's own state lies (a running mean of bytes) and stays.  When the two meet, bit for bit,
+// the state is the reference's -- proven, not assumed -- and the thread goes on through its piece
+// with it, writing the offsets every iteration starts from.  On bytes with some entropy the
+// bracket closes after about ln(255 / ulp) / (2 esr) iterations plus a few time constants of luck
+// (the run-in handed down by the host: a.warm).  On constant or near-constant bytes it never does:
+// the rounded recurrence stalls in a dead band around its fixed point and WHERE depends on where it
+// came from (round 2 started such run-ins from 127.5 and trusted them: offsets 1e-2 off the
+// reference's on a constant stream).  A bracket still open at the piece's start doubles
+// the run-in and starts over, until it reaches the call's first iteration, where the state is the
+// one the previous call left (carry_in): exact for every input, at the price of a long walk for
+// inputs that carry no information.
 // -ffp-contract=off: the reference's generic build rounds the sum, the product and the update
 // separately.  A piece is a part of a long chunk (a.parts threads share the chunk) or a.group
 // whole chunks: the host deals the stream out to a fixed budget of threads (api.cpp
-// run_offsets), the longest dependent chain is about warm + the piece.
+// run_offsets), the longest dependent chain is about the run-in + the piece.
 constexpr int kQ1Span = 64;  // iterations per span: 8 pairs of 16-byte loads, one from each end of the chunk
 
 struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t x, y, z, w; };  // a chunk's far end need not be 16-byte aligned
@@ -1550,58 +1561,54 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
     // run-in to its last one -- run-in and piece are cut in whole spans -- whichever chunk
     // boundaries it crosses on the way.  (Round 2's first form walked chunk by chunk: threads
     // that crossed at different times took turns, 124k iterations of wavefront time for 67k.)
-    const bool spans = (T % kQ1Span) == 0 && (a.warm % kQ1Span) == 0 && (((uintptr_t) a.in) & 15u) == 0;
+    const bool spans = (T % kQ1Span) == 0 && (a.warm % kQ1Span) == 0 && (a.retry % kQ1Span) == 0 && (((uintptr_t) a.in) & 15u) == 0;
     const uint64_t grain = spans ? (uint64_t) kQ1Span : 8u;
     const uint64_t per = ((Tc + a.parts - 1) / a.parts + grain - 1) / grain * grain;  // iterations per part
     const uint64_t p0 = (uint64_t) part * per;
     if (p0 >= Tc) return;
     const uint64_t p1 = c_last > c ? bytes_of(c_last) >> 2 : (p0 + per < Tc ? p0 + per : Tc);
-    float off0, off1;
-    uint64_t cc = 0, t0 = 0;                // where the run-in starts: chunk, iteration
-    if (c * T + p0 <= (uint64_t) a.warm) {
-        off0 = a.carry_in[0];
-        off1 = a.carry_in[1];
-    } else {
-        const uint64_t g = c * T + p0 - a.warm;
-        cc = g / T;
-        t0 = g - cc * T;
-        off0 = off1 = 127.5f;
-    }
-    // (off0, off1) as one packed pair: v_pk_add_f32 / v_pk_mul_f32 round each element exactly as
-    // the scalar operations do; a wavefront alone pays ~9 cycles per dependent operation either
-    // way (tools/microbench/chain_latency.hip), the packed form has fewer instructions beside them
-    pf2 off = {off0, off1};
+    // (lo, hi): the bracket during the run-in; `off` = lo is the state from the piece's start on.
+    // Each is the (re, im) offset pair as one packed pair: v_pk_add_f32 / v_pk_mul_f32 round each
+    // element exactly as the scalar operations do; a wavefront alone pays ~9 cycles per dependent
+    // operation either way (tools/microbench/chain_latency.hip), and the bracket's second copy is an
+    // independent chain that fills the first one's latency
+    pf2 off = {0.f, 0.f}, hi = {0.f, 0.f};
     const pf2 esr2 = {a.esr, a.esr};
-    auto update = [&](uint32_t fb0, uint32_t fb1, uint32_t mb0, uint32_t mb1) {
-        const pf2 f = pf2{(float) fb0, (float) fb1} - off;
-        const pf2 m = pf2{(float) mb0, (float) mb1} - off;
-        off = off + (f + m) * esr2;
+    auto update1 = [&](pf2 &o, uint32_t fb0, uint32_t fb1, uint32_t mb0, uint32_t mb1) {
+        const pf2 f = pf2{(float) fb0, (float) fb1} - o;
+        const pf2 m = pf2{(float) mb0, (float) mb1} - o;
+        o = o + (f + m) * esr2;
     };
     auto byte_of = [](const uint4 &v, int i) -> uint32_t {
         const uint32_t w = i < 4 ? v.x : i < 8 ? v.y : i < 12 ? v.z : v.w;
         return (w >> (8 * (i & 3))) & 0xFFu;
     };
     // eight iterations from one 16-byte block of each end; `row` (or null) receives the offsets
-    // every iteration starts from
+    // every iteration starts from; BRACKET: the second copy of the state moves along
     // (row is 16-byte aligned here: two iterations' offsets leave as one store -- the stores go to
     // 64 different cache lines per instruction, and there are as few of them as the data allows)
-    auto block = [&](const uint4 &f, const uint4 &m, float2 *row) {
+    auto block = [&](auto bracket_tag, const uint4 &f, const uint4 &m, float2 *row) {
+        constexpr bool BRACKET = decltype(bracket_tag)::value;
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             const pf2 before = off;
-            update(byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
+            update1(off, byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
+            if constexpr (BRACKET) update1(hi, byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
             if (row) *reinterpret_cast<float4 *>(row + j) = make_float4(before.x, before.y, off.x, off.y);
-            update(byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
+            update1(off, byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
+            if constexpr (BRACKET) update1(hi, byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
         }
     };
     // iterations [t0, t1) of a chunk, any alignment, any length: the path of chunks below 256
     // bytes and of what a stream's last chunk has beyond its whole spans
-    auto run = [&](const uint8_t *chunk, uint64_t len, uint64_t t0, uint64_t t1, float2 *row) {
+    auto run = [&](auto bracket_tag, const uint8_t *chunk, uint64_t len, uint64_t t0, uint64_t t1, float2 *row) {
+        constexpr bool BRACKET = decltype(bracket_tag)::value;
         uint64_t t = t0;
         auto single = [&]() {
             const uint8_t *f = chunk + 2 * t, *m = chunk + len - 2 * t - 2;
             if (row) row[t] = make_float2(off.x, off.y);
-            update(f[0], f[1], m[0], m[1]);
+            update1(off, f[0], f[1], m[0], m[1]);
+            if constexpr (BRACKET) update1(hi, f[0], f[1], m[0], m[1]);
             ++t;
         };
         const bool wide = (len & 15u) == 0 && (((uintptr_t) chunk) & 15u) == 0;
@@ -1614,7 +1621,7 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
                     const uint64_t tn = t + 16 <= t1 ? t + 8 : t;  // one block ahead
                     const uint4 fn = *reinterpret_cast<const uint4 *>(chunk + 2 * tn);
                     const uint4 mn = *reinterpret_cast<const uint4 *>(chunk + len - 2 * tn - 16);
-                    block(f, m, row ? row + t : nullptr);
+                    block(bracket_tag, f, m, row ? row + t : nullptr);
                     f = fn;
                     m = mn;
                 }
@@ -1623,75 +1630,95 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         while (t < t1) single();
     };
     float2 *const table = reinterpret_cast<float2 *>(a.table);
+    const uint64_t first = c * T + p0;   // where the written piece starts, in iterations of the whole call
+    // The thread is alone with a long dependent chain, so nothing but the arithmetic may be
+    // on it: a span's 16 loads are requested while the span before it is worked through
+    // (one pair of loads ahead left the chain waiting ~1 us for every pair), into register
+    // sets that take turns, with no branch between a request and its use (hipcc would sink
+    // the loads to the use).
+    auto request = [&](const Q1Pos &p, uint4 (&f)[8], uint4 (&m)[8]) {
+        const uint4 *fp = reinterpret_cast<const uint4 *>(p.chunk + 2 * p.t);
+        const Unaligned16 *mp = reinterpret_cast<const Unaligned16 *>(p.chunk + p.len - 2 * p.t - 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f[j] = fp[j];
+            const Unaligned16 u = mp[-j];
+            m[j] = make_uint4(u.x, u.y, u.z, u.w);
+        }
+    };
+    // the span after p: the next one of the chunk, or the first one of the next chunk (only
+    // chunks before this thread's last are ever finished here, and those are full ones)
+    auto after = [&](const Q1Pos &p) -> Q1Pos {
+        Q1Pos n = p;
+        n.t += kQ1Span;
+        if (n.t == T && p.cc < c_last) {
+            n.chunk += a.chunk_bytes;
+            n.cc = p.cc + 1;
+            n.len = bytes_of(n.cc);
+            n.t = 0;
+        }
+        return n;
+    };
+    Q1Pos cur{a.in, bytes_of(0), 0, 0};
+    auto phase = [&](auto write_tag, uint64_t left) {
+        constexpr bool kWrite = decltype(write_tag)::value;
+        if (left == 0) return;
+        auto work = [&](const uint4 (&f)[8], const uint4 (&m)[8], const Q1Pos &p) {
+            float2 *row = kWrite ? table + p.cc * a.stride + p.t : nullptr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) block(std::integral_constant<bool, !kWrite>{}, f[j], m[j], kWrite ? row + 8 * j : nullptr);
+        };
+        uint4 fa[8], ma[8], fb[8], mb[8];
+        request(cur, fa, ma);
+        while (left >= 2) {
+            const Q1Pos n1 = after(cur);
+            request(n1, fb, mb);
+            __builtin_amdgcn_sched_barrier(0);
+            work(fa, ma, cur);
+            const Q1Pos n2 = after(n1);
+            request(left > 2 ? n2 : n1, fa, ma);  // nothing beyond the phase is asked for (n1 again, dropped)
+            __builtin_amdgcn_sched_barrier(0);
+            work(fb, mb, n1);
+            cur = n2;
+            left -= 2;
+        }
+        if (left == 1) {
+            work(fa, ma, cur);
+            cur = after(cur);
+        }
+    };
+    // ---- the run-in: a bracket that has to close (see above) ---------------------------------
+    for (uint64_t warm = a.warm, attempt = 0;; ++attempt) {
+        const bool from_start = first <= warm;     // the run-in reaches the call's first iteration: the carried state, exact
+        const uint64_t g = from_start ? 0 : first - warm;
+        const uint64_t cc = g / T, t0 = g - cc * T;
+        off = from_start ? pf2{a.carry_in[0], a.carry_in[1]} : pf2{0.f, 0.f};
+        hi = from_start ? off : pf2{255.f, 255.f};
+        if (!spans) {
+            uint64_t w = cc, t = t0;
+            for (; w < c; ++w, t = 0) run(std::true_type{}, a.in + w * a.chunk_bytes, a.chunk_bytes, t, T, nullptr);
+            if (t < p0) run(std::true_type{}, a.in + c * a.chunk_bytes, len, t, p0, nullptr);   // the run-in's last stretch lies in this chunk
+        } else {
+            cur = Q1Pos{a.in + cc * a.chunk_bytes, bytes_of(cc), t0, cc};
+            phase(std::false_type{}, (first - g) / kQ1Span);
+        }
+        if (from_start || (__float_as_uint(off.x) == __float_as_uint(hi.x) && __float_as_uint(off.y) == __float_as_uint(hi.y))) break;
+        // still open: a little further back (a bracket that is an ulp wide closes at the rate of one time constant),
+        // then twice as far each time (bytes that carry no information: back to the call's first iteration)
+        warm = attempt == 0 ? warm + a.retry : warm > (~0ull >> 2) ? ~0ull : 2 * warm;
+    }
+    // ---- the piece ----------------------------------------------------------------------------
     if (!spans) {
-        for (; cc < c; ++cc, t0 = 0) run(a.in + cc * a.chunk_bytes, a.chunk_bytes, t0, T, nullptr);
-        if (t0 < p0) run(a.in + c * a.chunk_bytes, len, t0, p0, nullptr);   // the run-in's last stretch lies in this chunk
         for (uint64_t w = c; w <= c_last; ++w)
-            run(a.in + w * a.chunk_bytes, bytes_of(w), w == c ? p0 : 0, w == c_last ? p1 : T, table + w * a.stride);
+            run(std::false_type{}, a.in + w * a.chunk_bytes, bytes_of(w), w == c ? p0 : 0, w == c_last ? p1 : T, table + w * a.stride);
     } else {
-        // The thread is alone with a long dependent chain, so nothing but the arithmetic may be
-        // on it: a span's 16 loads are requested while the span before it is worked through
-        // (one pair of loads ahead left the chain waiting ~1 us for every pair), into register
-        // sets that take turns, with no branch between a request and its use (hipcc would sink
-        // the loads to the use).
-        auto request = [&](const Q1Pos &p, uint4 (&f)[8], uint4 (&m)[8]) {
-            const uint4 *fp = reinterpret_cast<const uint4 *>(p.chunk + 2 * p.t);
-            const Unaligned16 *mp = reinterpret_cast<const Unaligned16 *>(p.chunk + p.len - 2 * p.t - 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f[j] = fp[j];
-                const Unaligned16 u = mp[-j];
-                m[j] = make_uint4(u.x, u.y, u.z, u.w);
-            }
-        };
-        // the span after p: the next one of the chunk, or the first one of the next chunk (only
-        // chunks before this thread's last are ever finished here, and those are full ones)
-        auto after = [&](const Q1Pos &p) -> Q1Pos {
-            Q1Pos n = p;
-            n.t += kQ1Span;
-            if (n.t == T && p.cc < c_last) {
-                n.chunk += a.chunk_bytes;
-                n.cc = p.cc + 1;
-                n.len = bytes_of(n.cc);
-                n.t = 0;
-            }
-            return n;
-        };
-        Q1Pos cur{a.in + cc * a.chunk_bytes, bytes_of(cc), t0, cc};
-        auto phase = [&](auto write_tag, uint64_t left) {
-            constexpr bool kWrite = decltype(write_tag)::value;
-            if (left == 0) return;
-            auto work = [&](const uint4 (&f)[8], const uint4 (&m)[8], const Q1Pos &p) {
-                float2 *row = kWrite ? table + p.cc * a.stride + p.t : nullptr;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) block(f[j], m[j], kWrite ? row + 8 * j : nullptr);
-            };
-            uint4 fa[8], ma[8], fb[8], mb[8];
-            request(cur, fa, ma);
-            while (left >= 2) {
-                const Q1Pos n1 = after(cur);
-                request(n1, fb, mb);
-                __builtin_amdgcn_sched_barrier(0);
-                work(fa, ma, cur);
-                const Q1Pos n2 = after(n1);
-                request(left > 2 ? n2 : n1, fa, ma);  // nothing beyond the phase is asked for (n1 again, dropped)
-                __builtin_amdgcn_sched_barrier(0);
-                work(fb, mb, n1);
-                cur = n2;
-                left -= 2;
-            }
-            if (left == 1) {
-                work(fa, ma, cur);
-                cur = after(cur);
-            }
-        };
-        const uint64_t start = cc * T + t0, first = c * T + p0, last = c_last * T + p1;  // in iterations of the whole stream
-        phase(std::false_type{}, (first - start) / kQ1Span);
+        cur = Q1Pos{a.in + c * a.chunk_bytes, len, p0, c};
+        const uint64_t last = c_last * T + p1;  // in iterations of the whole stream
         const uint64_t whole = (last - first) / kQ1Span;
         phase(std::true_type{}, whole);
         // (what a stream's last chunk has beyond its whole spans)
         if (first + whole * kQ1Span < last)
-            run(a.in + c_last * a.chunk_bytes, bytes_of(c_last), first + whole * kQ1Span - c_last * T, p1, table + c_last * a.stride);
+            run(std::false_type{}, a.in + c_last * a.chunk_bytes, bytes_of(c_last), first + whole * kQ1Span - c_last * T, p1, table + c_last * a.stride);
     }
     if (c_last == total - 1 && p1 == (bytes_of(c_last) >> 2)) {
         a.carry_out[0] = off.x;

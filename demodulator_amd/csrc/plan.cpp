@@ -332,15 +332,24 @@ bool build_plan(const Options &o, Plan &plan, std::string &err) {
     plan.conditioning = iq_mode == 3 ? kNormalize : iq_mode == 2 ? kShiftOriginPlain : iq_mode == 1 ? kCorrectIq : kShiftOrigin;
     if (iq_mode == 1) {
         plan.esr = (float) (50. / o.sample_rate);  // src/matrix.c:210
-        // the offsets' recurrence off' = off (1 - 2 esr) + (byte + mirror byte) esr forgets its start:
-        // iterations until a difference of 255 has shrunk below 2^-26, twice over
+        // the offsets' recurrence off' = off (1 - 2 esr) + (byte + mirror byte) esr forgets its start at this rate
         const double decay = 2.0 * (double) plan.esr;
         if (!(decay > 1e-9) || !(decay < 1.0)) {
             err = "-q1: the sample rate puts the offset recurrence (src/matrix.c:137-138) outside 0 < 100/S < 1";
             return false;
         }
-        const double need = std::log(255.0 * 67108864.0) / -std::log1p(-decay);
-        plan.q1_warm = (uint32_t) (std::ceil(std::min(2.0 * need + 64.0, 4.0e9) / 64.0) * 64.0);  // whole spans of correct_iq_offsets
+        // The run-in of correct_iq_offsets (kernels.hip) carries a bracket [0, 255] of the state and has to see it
+        // close: a difference of 255 shrinks below an ulp of the offsets (2^-18 and less) in ln(255 * 2^18) = 18 time
+        // constants of 1 / (2 esr) iterations, and from an ulp apart two copies meet at the rate of one time
+        // constant.  A wavefront whose bracket is still open where its piece starts begins again from further back
+        // (q1_retry iterations further, then twice as far each time), and a dispatch lasts as long as its slowest
+        // wavefront: 13 more time constants leave the 16,384 threads of a dispatch a chance of 16384 e^-13 = 4 % that
+        // one of them has to.  (With 8: 2 % per wavefront, i.e. always one somewhere, 3.7 ms instead of 1.7 per 2^30
+        // bytes.  Round 2 ran 47 time constants from an arbitrary value and did not check.)
+        const double tau = 1.0 / -std::log1p(-decay);
+        const double need = (std::log(255.0 * 262144.0) + 13.0) * tau;
+        plan.q1_warm = (uint32_t) (std::ceil(std::min(need + 64.0, 4.0e9) / 64.0) * 64.0);  // whole spans of correct_iq_offsets
+        plan.q1_retry = (uint32_t) (std::ceil(std::min(8.0 * tau + 64.0, 4.0e9) / 64.0) * 64.0);
     }
     plan.prefilter = in_degree != 0 || iq_mode == 2;
     plan.in_separate = iq_mode == 2 && !cascade;

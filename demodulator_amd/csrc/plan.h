@@ -91,10 +91,10 @@ struct Plan {
     int head_quads = 0;    // ceil(H / 4): lanes of a chunk's first row whose outputs are chunk-head outputs (replayed literally)
     double magnitude_bound = 0;  // plan_magnitude_bound(): every float of the path stays below this
     // -q1: offsets move by (sum of the two corrected samples of an iteration) * esr, esr = (float)(50 / S)
-    // (src/matrix.c:137-138,210); after q1_warm iterations a start value has decayed below half an
-    // ulp of the offsets many times over ((1 - 2 esr)^n * 255 < 2^-26 at n = q1_warm / 2)
+    // (src/matrix.c:137-138,210); q1_warm: the first run-in correct_iq_offsets gives its bracket of the state to
+    // close (about 26 time constants of 1 / (2 esr) iterations; doubled while it stays open, build_plan)
     float esr = 0.f;
-    uint32_t q1_warm = 0;
+    uint32_t q1_warm = 0, q1_retry = 0;
 };
 
 // Bound on the magnitude of every intermediate and result of the path for a plan (finite

@@ -335,6 +335,14 @@ class Demodulator:
                                                    out.ctypes.data, y.size), "demod_selftest_atan2")
         return out
 
+    def selftest_q1_offsets(self, n_pairs: int):
+        """-q1: (offsets of the last call as an (n_pairs, 2) float32 array, the state it left as a (2,) array)."""
+        pairs = np.zeros((n_pairs, 2), dtype=np.float32)
+        state = np.zeros(2, dtype=np.float32)
+        self._check(self._lib.demod_selftest_q1_offsets(self._ctx, pairs.ctypes.data if n_pairs else None, n_pairs, state.ctypes.data),
+                    "demod_selftest_q1_offsets")
+        return pairs, state
+
     def selftest_lane_shift(self, v: np.ndarray, halo: float) -> np.ndarray:
         v = np.ascontiguousarray(v, dtype=np.float32)
         out = np.empty(64, dtype=np.float32)

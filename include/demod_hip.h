@@ -351,6 +351,11 @@ int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t 
 int demod_selftest_atan2(demod_ctx *ctx, const float *h_y, const float *h_x, float *h_out,
                          uint32_t n);
 int demod_selftest_lane_shift(demod_ctx *ctx, const float *h_in64, float halo, float *h_out64);
+/* -q1 only (test-suite): the running offsets the most recent process call replayed -- n_pairs (re, im) pairs, one
+ * per iteration of correctIq in stream order (iteration t of chunk c at pair c * chunk_bytes / 4 + t: the offsets
+ * complex samples t and K-1-t of that chunk were corrected with, src/matrix.c:131-135) -- and the state the call
+ * left for the next one (h_state2, two floats).  Waits for the device.  Either pointer may be null. */
+int demod_selftest_q1_offsets(demod_ctx *ctx, float *h_pairs, uint64_t n_pairs, float *h_state2);
 
 /* Average time in milliseconds the fused kernel took per process call, over the
  * calls issued since the previous call to this function, measured with HIP

@@ -77,6 +77,8 @@ class _Lib:
         f("unpack_shift", None, [C.c_void_p, C.c_size_t, C.c_void_p])
         f("unpack_normalize", None, [C.c_void_p, C.c_size_t, C.c_void_p])
         f("discriminate", None, [C.c_void_p, C.c_size_t, C.c_void_p])
+        if prefix == "orc":
+            f("unpack_correct_iq", None, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_void_p])
         f("filter_real", None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p])
         f("filter_complex", None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p])
         f("process_stream", C.c_longlong, [C.POINTER(_Params), C.c_void_p, C.c_size_t,
@@ -111,6 +113,20 @@ class _Lib:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         out = np.zeros(data.size, dtype=np.float32)
         self._unpack_normalize(data.ctypes.data, data.size, out.ctypes.data)
+        return out
+
+    def unpack_correct_iq(self, data: np.ndarray, chunk_bytes: int, sample_rate: float) -> np.ndarray:
+        """-q1 (correctIq, src/matrix.c:120-140) alone: the corrected samples byte - running offset of a whole stream,
+        chunk after chunk, the offsets starting at zero and carried from chunk to chunk as the reference's static
+        pair is.  (The restatement's function: bit-identical to the reference's, tests/test_oracle_golden.py.)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.zeros(data.size, dtype=np.float32)
+        off = np.zeros(2, dtype=np.float32)
+        esr = np.float32(50.0 / sample_rate)
+        for pos in range(0, data.size & ~3, chunk_bytes):
+            ln = min(chunk_bytes, (data.size & ~3) - pos)
+            self._unpack_correct_iq(data.ctypes.data + pos, ln, out.ctypes.data + 4 * pos, esr, off.ctypes.data)
+        self.last_correct_iq_state = off      # the pair the next chunk would start from
         return out
 
     def discriminate(self, x: np.ndarray) -> np.ndarray:

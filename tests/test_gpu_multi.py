@@ -77,3 +77,13 @@ def test_forced_peer_copy_and_channels(monkeypatch):
         with dm.Demodulator(opt) as d:
             whole = d.process(torch.from_numpy(stream).cuda(), chunk_offset=1024).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
+def test_q1_is_refused_over_several_devices():
+    """-q1's running offsets belong to ONE stream walked in order (src/matrix.c:125: static state): every shard but the
+    first would start them from zero, and a device's batched channels would hand them from one channel to the next.
+    demod_multi_create refuses the option set instead of computing something else silently."""
+    with pytest.raises(dm.DemodError, match="cannot be sharded"):
+        dm.MultiDemodulator(dm.Options(mode=0x14), [0])
+    with pytest.raises(dm.DemodError, match="cannot be sharded"):
+        dm.MultiDemodulator(dm.Options(mode=0x14, **C3), [0, 0])

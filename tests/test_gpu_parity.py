@@ -947,6 +947,90 @@ def test_correct_iq_q1(orc, kw, n_bytes):
             assert np.array_equal(np.concatenate(parts).view(np.uint32), whole.view(np.uint32))
 
 
+def _q1_streams(B: int, n_chunks: int):
+    """Streams correctIq's running offsets learn nothing from (the rounded recurrence stalls in a dead band around its
+    fixed point, and where depends on where it came from), and mixtures with streams they do learn from."""
+    n = n_chunks * B
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, n, dtype=np.uint8)
+    const = np.full(n, 100, dtype=np.uint8)
+    two = np.tile(np.array([100, 200], dtype=np.uint8), n // 2)                   # I = 100, Q = 200 throughout
+    toggle = np.tile(np.array([127, 127, 128, 128], dtype=np.uint8), n // 4)     # 1 LSB up and down, sample by sample
+    burst = const.copy()
+    burst[n // 2:n // 2 + 3 * B] = noise[:3 * B]                                 # constant, three chunks of noise, constant again
+    late = noise.copy()
+    late[n // 3:] = 37                                                           # noise that falls silent
+    steps = np.repeat(rng.integers(90, 110, n // (B // 2), dtype=np.uint8), B // 2)   # a new constant every half chunk
+    return {"constant": const, "two_level": two, "lsb_toggle": toggle, "noise_burst": burst, "falls_silent": late, "steps": steps,
+            "noise": noise}
+
+
+@pytest.mark.parametrize("pattern", ["constant", "two_level", "lsb_toggle", "noise_burst", "falls_silent", "steps", "noise"])
+def test_correct_iq_offsets_are_the_references_on_streams_without_entropy(orc, pattern):
+    """-q1: the offsets every sample is corrected with are the reference's TO THE BIT, whatever the stream -- also
+    where a run-in cannot forget its start (a constant byte 100 stalls at 99.99524 coming from below and at
+    100.00476 coming from above, 1e-3 relative in byte - offset).  correct_iq_offsets carries a bracket of the state
+    through its run-in and only trusts it once it has closed, walking further back -- to the call's own start, where
+    the state is the carried one -- while it has not (kernels.hip).  Checked on the offsets themselves (the selftest
+    hands back the table the call replayed): byte - offset against the restatement's correctIq, bit for bit, for one
+    call, for the same stream in several calls (the state each call leaves included) and through the ring's batches;
+    streams long enough for every piece of a chunk to start beyond a first run-in."""
+    import threading
+
+    import torch
+    S = 125000.0
+    opt = dm.Options(mode=0x14, buf_size=65536, sample_rate=S)
+    B, n_chunks = opt.buf_size, 24
+    data = _q1_streams(B, n_chunks)[pattern]
+    want = orc.unpack_correct_iq(data, B, S)
+    want_state = orc.last_correct_iq_state.copy()
+    T, K = B // 4, B // 2
+
+    def corrected(table, first_chunk, chunks):
+        k = np.arange(K)
+        t = np.minimum(k, K - 1 - k)
+        out = np.empty(chunks * B, dtype=np.float32)
+        for c in range(chunks):
+            by = data[(first_chunk + c) * B:(first_chunk + c + 1) * B].astype(np.float32)
+            tab = table[c * T:(c + 1) * T]
+            out[c * B:(c + 1) * B:2] = by[0::2] - tab[t, 0]
+            out[c * B + 1:(c + 1) * B:2] = by[1::2] - tab[t, 1]
+        return out
+
+    iq = torch.from_numpy(data).cuda()
+    with dm.Demodulator(opt) as d:
+        d.process(iq)
+        table, state = d.selftest_q1_offsets(n_chunks * T)
+        got = corrected(table, 0, n_chunks)
+        bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+        assert bad.size == 0, (pattern, bad[:8], got[bad[:4]], want[bad[:4]])
+        assert np.array_equal(state.view(np.uint32), want_state.view(np.uint32)), (pattern, state, want_state)
+    # the same stream in several calls: every call's offsets, and the state it hands on
+    cuts = [0, 5, 6, 17, n_chunks]
+    with dm.Demodulator(opt) as d:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            d.process(iq[a * B:b * B].clone(), end_of_stream=(b == n_chunks))
+            table, state = d.selftest_q1_offsets((b - a) * T)
+            got = corrected(table, a, b - a)
+            assert np.array_equal(got.view(np.uint32), want[a * B:b * B].view(np.uint32)), (pattern, a, b)
+            orc.unpack_correct_iq(data[:b * B], B, S)
+            assert np.array_equal(state.view(np.uint32), orc.last_correct_iq_state.view(np.uint32)), (pattern, a, b)
+    # through the ring (batches of hand-offs, whatever sizes the pipeline makes of them): the state it ends with
+    with dm.Demodulator(opt) as d, d.ring() as ring:
+        def consume():
+            while ring.take() is not None:
+                pass
+        th = threading.Thread(target=consume)
+        th.start()
+        for pos in range(0, n_chunks * B, B):
+            ring.put(data[pos:pos + B], final=False)
+        ring.put(np.zeros(0, np.uint8), final=True)
+        th.join(timeout=120)
+        assert not th.is_alive()
+        _, state = d.selftest_q1_offsets(0)
+        assert np.array_equal(state.view(np.uint32), want_state.view(np.uint32)), (pattern, "ring", state, want_state)
+
+
 @pytest.mark.parametrize("kw", [
     dict(), C3, dict(lowpass_in=12500.0, lowpass_out=6500.0, in_degree=8, out_degree=7),
     dict(lowpass_in=9600.0, in_degree=5, out_degree=2, mode=0x13), dict(mode=0x18), dict(mode=0x1C, lowpass_in=12500.0),
