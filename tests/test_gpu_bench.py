@@ -76,3 +76,28 @@ def test_two_ranks_under_torch_distributed_run_as_the_driver_launches_them():
     assert r.returncode == 0 and len(lines) == 1, (lines, r.stderr.decode()[-2000:])   # one line on stdout, nothing else
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["halo_exchange"].startswith("gloo send/recv") and line["value"] > 0
+    # what the first real multi-GPU run has to tell: the size of the RCCL group as created (0 in this
+    # rehearsal: the halos travel over gloo), every rank's own step and kernel time, the cost of an exchange
+    m = line["multi"]
+    assert m["rccl_ranks"] == 0 and m["control_ranks"] == 2
+    assert 0 < m["ms_per_step_min"] <= m["ms_per_step_max"] and 0 < m["kernel_ms_per_dispatch_min"] <= m["kernel_ms_per_dispatch_max"]
+    assert m["halo_us_per_step"] is not None and m["halo_us_per_step"] > 0
+
+
+def test_single_process_over_the_c_level_multi_gpu_entry():
+    """`python bench.py --gpus 2 --single-process`: the same line from ONE process driving both shards through
+    demod_multi_* (multi.cpp).  With one device here the two contexts share it (the line says REHEARSAL, RCCL refuses
+    the device list and the halos travel by peer copy); on an 8-GPU node the same command times the native grouped
+    ncclSend/ncclRecv path."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--single-process", "--workload", "c3", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout.decode()[-500:], r.stderr.decode()[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["multi"]["mode"].startswith("one process") and line["multi"]["halo_transport"] == "peer-copy"
+    assert line["multi"]["devices_distinct"] is False and "REHEARSAL" in line["multi"]["note"]
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--single-process", "--workload", "c2", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    line = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert r.returncode == 0 and line["n_gpus"] == 1 and line["multi"]["devices_distinct"] and line["multi"]["halo_transport"] == "none"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-phase VALU instruction table of a demod_rows instantiation, from `hipcc -S`.
 
-    python tools/isa_table.py                       # target build: demod_rows<2,2,plain,false,false,false>
+    python tools/isa_table.py                       # target build: demod_rows<2,2,normalized,false,false,false>
+    python tools/isa_table.py --cond 1              # the plain form of the same design (round 2's default)
     python tools/isa_table.py --tin 0 --cond 0      # BASELINE config 2's build
     python tools/isa_table.py --asm /tmp/k.s        # reuse an assembly file (skips the 1-minute compile)
 
@@ -132,7 +133,7 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--tin", type=int, default=2)
     ap.add_argument("--tout", type=int, default=2)
-    ap.add_argument("--cond", type=int, default=1, help="0 shiftOrigin (folded where a complex stage exists), 1 plain, 3 normalize")
+    ap.add_argument("--cond", type=int, default=2, help="0 shiftOrigin (folded where a complex stage exists), 1 plain, 2 stencil divided by its first tap (the default with -L), 3 normalizeInput")
     ap.add_argument("--s16", action="store_true")
     ap.add_argument("--span", action="store_true")
     ap.add_argument("--asm", help="assembly file to read instead of compiling")
