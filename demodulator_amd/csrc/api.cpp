@@ -365,6 +365,8 @@ static int run_offsets(demod_ctx *ctx, const uint8_t *d_in, uint64_t n_bytes, ui
     else
         o.parts = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>({256, (B / 4) / 4096, DEMOD_Q1_THREADS / std::max<uint64_t>(1, chunks)}));
     o.esr = pl.esr;
+    o.widen = pl.esr * (1.0f / 2048.0f);    // 2 J, J <= esr 2^-12: what the roundings of the small terms can undo (kernels.hip)
+    o.floor2 = pl.esr * 8192.0f;            // twice esr 2^12: above esr 2^12 one ulp of the offsets exceeds J
     if (launch_offsets(o, stream)) {
         ctx->fail(DEMOD_E_HIP, "correct_iq_offsets launch", hipGetLastError());
         return DEMOD_E_HIP;

@@ -115,6 +115,8 @@ struct OffsetLaunch {
     uint32_t parts;            // threads that share one chunk (>= 1) ...
     uint32_t group;            // ... or chunks one thread walks through (>= 1; one of the two is 1)
     float esr;
+    float widen;               // the bracket's widening per iteration during its first span (>= 2 J, kernels.hip) ...
+    float floor2;              // ... and twice the offset above which the rounded step is monotone (the lower copy's floor)
 };
 
 // Host-callable launchers (defined in kernels.hip).  `stream` is a hipStream_t.

@@ -1513,14 +1513,21 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
 //     off += ((byte[t] - off) + (byte[K-1-t] - off)) * esr        (re and im lanes alike),
 // and its static offsets carry on from chunk to chunk: a float recurrence over the whole stream,
 // every step rounded, so it cannot be re-associated.  It contracts, though -- a start value is
-// forgotten at the rate (1 - 2 esr) per iteration -- and the rounded step is monotone in the offset
-// (a larger offset never comes out smaller: each of its roundings is monotone, and for offsets a
-// whole ulp apart the exact step's (1 - 2 esr) ulp dwarfs what the roundings of the small terms can
-// undo).  So a thread replays the literal operations over a RUN-IN before the piece of the stream
-// it writes, on a BRACKET: two copies of the state, started at 0 and at 255, between which the
-// reference's own state lies (a running mean of bytes) and stays.  When the two meet, bit for bit,
-// the state is the reference's -- proven, not assumed -- and the thread goes on through its piece
-// with it, writing the offsets every iteration starts from.  On bytes with some entropy the
+// forgotten at the rate (1 - 2 esr) per iteration -- and the rounded step g is monotone in the
+// offset wherever the offset is not tiny: g(x) = fl(x + p(x)) with p = fl(fl(fl(b - x) + fl(m - x)) esr)
+// a non-increasing step function of x; for x <= y the exact sums satisfy
+//     (y + p(y)) - (x + p(x)) >= (y - x)(1 - 2 esr) - J,   J = esr (2^-14 + 510 2^-22) <= esr 2^-12
+// (what the roundings of b - x, m - x, their sum and the product can undo), so g(y) >= g(x) as soon
+// as one ulp of the offsets exceeds J, i.e. for offsets above a.floor2 / 2 = esr 2^12 (1.6 at 125 kS/s:
+// a float32 sweep finds no inversion above 0.8 in 3.6e8 pairs and 2e-6 of them below), and
+// g(y) >= g(x) - J always.  So a thread replays the literal operations over
+// a RUN-IN before the piece of the stream it writes, on a BRACKET: two copies of the state, started
+// at 0 and at 255, between which the reference's own state lies (a running mean of bytes) and
+// stays -- the first kQ1Careful iterations of the run-in push the lower copy down by a.widen >= 2 J
+// per iteration (it starts at 0, below the monotone range), and from then on it has to stay above
+// a.floor2 (checked every eight iterations: it cannot halve in between), else nothing is concluded.  When the
+// two copies meet, bit for bit, the state is the reference's -- proven, not assumed -- and the
+// thread goes on through its piece with it, writing the offsets every iteration starts from.  On bytes with some entropy the
 // bracket closes after about ln(255 / ulp) / (2 esr) iterations plus a few time constants of luck
 // (the run-in handed down by the host: a.warm).  On constant or near-constant bytes it never does:
 // the rounded recurrence stalls in a dead band around its fixed point and WHERE depends on where it
@@ -1534,6 +1541,7 @@ __global__ __launch_bounds__(64) void demod_tiny(const TinyLaunch a) {
 // whole chunks: the host deals the stream out to a fixed budget of threads (api.cpp
 // run_offsets), the longest dependent chain is about the run-in + the piece.
 constexpr int kQ1Span = 64;  // iterations per span: 8 pairs of 16-byte loads, one from each end of the chunk
+constexpr int kQ1Careful = 4 * kQ1Span;  // iterations at the start of a run-in that widen the bracket (see above)
 
 struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t x, y, z, w; };  // a chunk's far end need not be 16-byte aligned
 
@@ -1573,12 +1581,20 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
     // operation either way (tools/microbench/chain_latency.hip), and the bracket's second copy is an
     // independent chain that fills the first one's latency
     pf2 off = {0.f, 0.f}, hi = {0.f, 0.f};
+    float lowest = 0.f;        // of the bracket's lower copy, sampled every eight iterations behind the widened ones (a running minimum: no branch in the loop)
     const pf2 esr2 = {a.esr, a.esr};
     auto update1 = [&](pf2 &o, uint32_t fb0, uint32_t fb1, uint32_t mb0, uint32_t mb1) {
         const pf2 f = pf2{(float) fb0, (float) fb1} - o;
         const pf2 m = pf2{(float) mb0, (float) mb1} - o;
         o = o + (f + m) * esr2;
     };
+    // bracket tags: 0 = one state (the piece), 1 = the bracket, 2 = the bracket, widened every iteration (first span)
+    typedef std::integral_constant<int, 0> OneState;
+    typedef std::integral_constant<int, 1> Bracket;
+    typedef std::integral_constant<int, 2> BracketWidened;
+    // (only the lower copy: the upper one is in the monotone range whenever the lower one's floor holds.  A relative
+    // step as well as an absolute one: fl(x - W) must really be below x - J wherever x is, and W < ulp(x) / 2 above 8)
+    auto widen = [&]() { off = off * pf2{1.f - 0x1p-20f, 1.f - 0x1p-20f} - pf2{a.widen, a.widen}; };
     auto byte_of = [](const uint4 &v, int i) -> uint32_t {
         const uint32_t w = i < 4 ? v.x : i < 8 ? v.y : i < 12 ? v.z : v.w;
         return (w >> (8 * (i & 3))) & 0xFFu;
@@ -1588,27 +1604,32 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
     // (row is 16-byte aligned here: two iterations' offsets leave as one store -- the stores go to
     // 64 different cache lines per instruction, and there are as few of them as the data allows)
     auto block = [&](auto bracket_tag, const uint4 &f, const uint4 &m, float2 *row) {
-        constexpr bool BRACKET = decltype(bracket_tag)::value;
+        constexpr int BRACKET = decltype(bracket_tag)::value;
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             const pf2 before = off;
             update1(off, byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
-            if constexpr (BRACKET) update1(hi, byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
+            if constexpr (BRACKET != 0) update1(hi, byte_of(f, 2 * j), byte_of(f, 2 * j + 1), byte_of(m, 14 - 2 * j), byte_of(m, 15 - 2 * j));
+            if constexpr (BRACKET == 2) widen();
             if (row) *reinterpret_cast<float4 *>(row + j) = make_float4(before.x, before.y, off.x, off.y);
             update1(off, byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
-            if constexpr (BRACKET) update1(hi, byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
+            if constexpr (BRACKET != 0) update1(hi, byte_of(f, 2 * j + 2), byte_of(f, 2 * j + 3), byte_of(m, 12 - 2 * j), byte_of(m, 13 - 2 * j));
+            if constexpr (BRACKET == 2) widen();
         }
+        if constexpr (BRACKET == 1) lowest = fminf(lowest, fminf(off.x, off.y));
     };
     // iterations [t0, t1) of a chunk, any alignment, any length: the path of chunks below 256
     // bytes and of what a stream's last chunk has beyond its whole spans
     auto run = [&](auto bracket_tag, const uint8_t *chunk, uint64_t len, uint64_t t0, uint64_t t1, float2 *row) {
-        constexpr bool BRACKET = decltype(bracket_tag)::value;
+        constexpr int BRACKET = decltype(bracket_tag)::value;
         uint64_t t = t0;
         auto single = [&]() {
             const uint8_t *f = chunk + 2 * t, *m = chunk + len - 2 * t - 2;
             if (row) row[t] = make_float2(off.x, off.y);
             update1(off, f[0], f[1], m[0], m[1]);
-            if constexpr (BRACKET) update1(hi, f[0], f[1], m[0], m[1]);
+            if constexpr (BRACKET != 0) update1(hi, f[0], f[1], m[0], m[1]);
+            if constexpr (BRACKET == 2) widen();
+            if constexpr (BRACKET == 1) lowest = fminf(lowest, fminf(off.x, off.y));
             ++t;
         };
         const bool wide = (len & 15u) == 0 && (((uintptr_t) chunk) & 15u) == 0;
@@ -1666,7 +1687,7 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         auto work = [&](const uint4 (&f)[8], const uint4 (&m)[8], const Q1Pos &p) {
             float2 *row = kWrite ? table + p.cc * a.stride + p.t : nullptr;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) block(std::integral_constant<bool, !kWrite>{}, f[j], m[j], kWrite ? row + 8 * j : nullptr);
+            for (int j = 0; j < 8; ++j) block(std::integral_constant<int, kWrite ? 0 : 1>{}, f[j], m[j], kWrite ? row + 8 * j : nullptr);
         };
         uint4 fa[8], ma[8], fb[8], mb[8];
         request(cur, fa, ma);
@@ -1694,15 +1715,34 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         const uint64_t cc = g / T, t0 = g - cc * T;
         off = from_start ? pf2{a.carry_in[0], a.carry_in[1]} : pf2{0.f, 0.f};
         hi = from_start ? off : pf2{255.f, 255.f};
-        if (!spans) {
+        lowest = 3.0e38f;
+        // the first kQ1Careful iterations widen the bracket (its lower copy starts below the monotone range) ...
+        uint64_t careful = from_start ? 0 : (first - g < (uint64_t) kQ1Careful ? first - g : (uint64_t) kQ1Careful);
+        const uint64_t plain_spans = (first - g - careful) / kQ1Span;
+        {
             uint64_t w = cc, t = t0;
-            for (; w < c; ++w, t = 0) run(std::true_type{}, a.in + w * a.chunk_bytes, a.chunk_bytes, t, T, nullptr);
-            if (t < p0) run(std::true_type{}, a.in + c * a.chunk_bytes, len, t, p0, nullptr);   // the run-in's last stretch lies in this chunk
-        } else {
-            cur = Q1Pos{a.in + cc * a.chunk_bytes, bytes_of(cc), t0, cc};
-            phase(std::false_type{}, (first - g) / kQ1Span);
+            while (careful) {   // (a span lies in one chunk when chunks are whole spans; tiny chunks: piece by piece)
+                const uint64_t Tw = bytes_of(w) >> 2;
+                const uint64_t n = careful < Tw - t ? careful : Tw - t;
+                run(BracketWidened{}, a.in + w * a.chunk_bytes, bytes_of(w), t, t + n, nullptr);
+                careful -= n;
+                t += n;
+                if (t == Tw) {
+                    ++w;
+                    t = 0;
+                }
+            }
+            // ... and the rest runs on the plain bracket, its lower copy checked against the floor
+            if (!spans) {
+                for (; w < c; ++w, t = 0) run(Bracket{}, a.in + w * a.chunk_bytes, a.chunk_bytes, t, T, nullptr);
+                if (w == c && t < p0) run(Bracket{}, a.in + c * a.chunk_bytes, len, t, p0, nullptr);   // the run-in's last stretch lies in this chunk
+            } else if (plain_spans) {
+                cur = Q1Pos{a.in + w * a.chunk_bytes, bytes_of(w), t, w};
+                phase(std::false_type{}, plain_spans);
+            }
         }
-        if (from_start || (__float_as_uint(off.x) == __float_as_uint(hi.x) && __float_as_uint(off.y) == __float_as_uint(hi.y))) break;
+        // closed, and the lower copy never left the range where the step is monotone: the state is the reference's
+        if (from_start || (lowest >= a.floor2 && __float_as_uint(off.x) == __float_as_uint(hi.x) && __float_as_uint(off.y) == __float_as_uint(hi.y))) break;
         // still open: a little further back (a bracket that is an ulp wide closes at the rate of one time constant),
         // then twice as far each time (bytes that carry no information: back to the call's first iteration)
         warm = attempt == 0 ? warm + a.retry : warm > (~0ull >> 2) ? ~0ull : 2 * warm;
@@ -1710,7 +1750,7 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
     // ---- the piece ----------------------------------------------------------------------------
     if (!spans) {
         for (uint64_t w = c; w <= c_last; ++w)
-            run(std::false_type{}, a.in + w * a.chunk_bytes, bytes_of(w), w == c ? p0 : 0, w == c_last ? p1 : T, table + w * a.stride);
+            run(OneState{}, a.in + w * a.chunk_bytes, bytes_of(w), w == c ? p0 : 0, w == c_last ? p1 : T, table + w * a.stride);
     } else {
         cur = Q1Pos{a.in + c * a.chunk_bytes, len, p0, c};
         const uint64_t last = c_last * T + p1;  // in iterations of the whole stream
@@ -1718,7 +1758,7 @@ __global__ __launch_bounds__(64) void correct_iq_offsets(const OffsetLaunch a) {
         phase(std::true_type{}, whole);
         // (what a stream's last chunk has beyond its whole spans)
         if (first + whole * kQ1Span < last)
-            run(std::false_type{}, a.in + c_last * a.chunk_bytes, bytes_of(c_last), first + whole * kQ1Span - c_last * T, p1, table + c_last * a.stride);
+            run(OneState{}, a.in + c_last * a.chunk_bytes, bytes_of(c_last), first + whole * kQ1Span - c_last * T, p1, table + c_last * a.stride);
     }
     if (c_last == total - 1 && p1 == (bytes_of(c_last) >> 2)) {
         a.carry_out[0] = off.x;

@@ -961,11 +961,16 @@ def _q1_streams(B: int, n_chunks: int):
     late = noise.copy()
     late[n // 3:] = 37                                                           # noise that falls silent
     steps = np.repeat(rng.integers(90, 110, n // (B // 2), dtype=np.uint8), B // 2)   # a new constant every half chunk
+    zeros = np.zeros(n, dtype=np.uint8)                                           # the state never leaves 0: below the bracket's floor
+    low = rng.integers(0, 4, n, dtype=np.uint8)                                  # a mean of 1.5: noise, but below the floor
+    dips = noise.copy()
+    dips[n // 4:n // 4 + 2 * B] = 0                                              # the state decays towards 0 and comes back
     return {"constant": const, "two_level": two, "lsb_toggle": toggle, "noise_burst": burst, "falls_silent": late, "steps": steps,
-            "noise": noise}
+            "noise": noise, "zeros": zeros, "low_dc": low, "dips_to_zero": dips}
 
 
-@pytest.mark.parametrize("pattern", ["constant", "two_level", "lsb_toggle", "noise_burst", "falls_silent", "steps", "noise"])
+@pytest.mark.parametrize("pattern", ["constant", "two_level", "lsb_toggle", "noise_burst", "falls_silent", "steps", "noise", "zeros", "low_dc",
+                                     "dips_to_zero"])
 def test_correct_iq_offsets_are_the_references_on_streams_without_entropy(orc, pattern):
     """-q1: the offsets every sample is corrected with are the reference's TO THE BIT, whatever the stream -- also
     where a run-in cannot forget its start (a constant byte 100 stalls at 99.99524 coming from below and at
