@@ -273,6 +273,13 @@ static bool heads_are_fused(const demod_ctx *ctx) {
     if (!can || ctx->head_mode == 0 || ctx->head_mode == 2) return false;
     if (ctx->head_mode == 1) return true;
     const uint64_t rows_per_chunk = ctx->seamless ? (1ull << 31) : pl.chunk_bytes / kRowBytes;
+    // Round 3 (tools/head_pack_probe.py, profiles/r3_head_modes.txt): without a complex stage a head is a few dozen
+    // operations and the streaming kernel wins at every chunk size (1 KiB: 0.70 -> 0.76 of peak, 4 KiB: 0.78 -> 0.81,
+    // 256 KiB: 0.81 -> 0.82); with one it wins where a head is rare (256 rows and more) and at one-row chunks, whose
+    // four heads per segment are replayed side by side in ONE pass (0.61 -> 0.62-0.65); in between the head kernel
+    // stays ahead (2 KiB: 0.71 against 0.65, 16 KiB: 0.78 against 0.71).
+    if (pl.in.sections == 0) return true;
+    if (rows_per_chunk == 1 && 4 * pl.head_quads + pl.in.sections + pl.out.sections + 2 <= 16) return true;
     return rows_per_chunk >= kFusedMinRows;
 }
 
@@ -301,6 +308,7 @@ static void fill_stencils(const demod_ctx *ctx, RowLaunch &r) {
     // demod_heads runs behind the streaming kernel and overwrites the head outputs
     r.head_quads = (uint32_t) pl.head_quads;
     r.fused_heads = heads_are_fused(ctx) ? 1u : 0u;
+    r.heads_packed = (4 * pl.head_quads + pl.in.sections + pl.out.sections + 2 <= 16) ? 1u : 0u;
     r.sec_in = pl.in.sections;
     r.sec_out = pl.out.sections;
     r.in_separate = pl.in_separate;

@@ -29,6 +29,9 @@ struct RowLaunch {
     uint32_t head_quads;   // lanes of a chunk's row 0 whose outputs are chunk-head outputs (ceil(H / 4))
     // chunk head replayed by the wavefront that owns the chunk's row 0 (kernels.hip chunk_head); 0: left to demod_heads
     uint32_t fused_heads;
+    // chunks shorter than a segment: the heads of a segment's chunks side by side, sixteen lanes each, in one pass
+    // (a head's reach 4 head_quads + sec_in + sec_out + 2 has to fit sixteen lanes); 0: one pass per chunk
+    uint32_t heads_packed;
     int32_t sec_in, sec_out;  // sections of the complex stage (0 = none) and of the output stage
     int32_t in_separate;      // Plan::in_separate
     float sos_in[4][6], sos_out[4][6];

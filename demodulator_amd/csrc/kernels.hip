@@ -773,8 +773,13 @@ __device__ __forceinline__ float section_update(const float (&row)[6], float cur
 // samples, and finds highpassDc's overflow cells -- three constants of the design, its inputs
 // behind its buffer being zeros -- where its own output starts (src/matrix.c:155-156, :260-264:
 // filterRet + bufSize is both).
+// `lane` counts from the head's own lane 0, which is lane `lane_base` of the wavefront: with chunks shorter than a
+// segment the heads of a segment's chunks are replayed side by side, sixteen lanes each (`chunk`, `out_index` and
+// `n_out` are then per-lane values).  The neighbour fetches shift the whole wavefront, so a head's lane 15 receives
+// the next head's lane 0: harmless where output n only reaches lanes up to n + sec_in + sec_out + 1 < 16.
 template <int COND, bool S16, int MAXSEC = kFusedSections, class LAUNCH = RowLaunch, bool PRE = false>
-__device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane, uint32_t n_out) {
+__device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane, uint32_t n_out,
+                                           uint32_t lane_base = 0u) {
     // the segment's own stores (among them the interior-formula values of this row's first
     // lanes, which are overwritten below) are complete before anything here is stored
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -859,8 +864,8 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
         // output, x[K + t] == z[t] (the buffers are adjacent, src/matrix.c:260-264) -- or zeros
         // when the stage reads a buffer of its own (-q2).  Cell t lives in lane t / 2.
         const uint32_t s0 = lane >> 1, s1 = (lane + 1u) >> 1;
-        const float rA0 = lane_read(Ar, s0), rB0 = lane_read(Br, s0), iA0 = lane_read(Ai, s0), iB0 = lane_read(Bi, s0);
-        const float rA1 = lane_read(Ar, s1), rB1 = lane_read(Br, s1), iA1 = lane_read(Ai, s1), iB1 = lane_read(Bi, s1);
+        const float rA0 = lane_read(Ar, lane_base + s0), rB0 = lane_read(Br, lane_base + s0), iA0 = lane_read(Ai, lane_base + s0), iB0 = lane_read(Bi, lane_base + s0);
+        const float rA1 = lane_read(Ar, lane_base + s1), rB1 = lane_read(Br, lane_base + s1), iA1 = lane_read(Ai, lane_base + s1), iB1 = lane_read(Bi, lane_base + s1);
         const bool own = a.in_separate == 0;
         const float ztr = own ? ((lane & 1u) ? rB0 : rA0) : 0.f, zti = own ? ((lane & 1u) ? iB0 : iA0) : 0.f;
         const float zur = own ? ((lane & 1u) ? rA1 : rB1) : 0.f, zui = own ? ((lane & 1u) ? iA1 : iB1) : 0.f;
@@ -877,7 +882,7 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
             }
         }
         // output cell n starts from overflow cell n / 2: its real part (n even) or imaginary part (n odd)
-        const float ovr = lane_read(cr, lane >> 1), ovi = lane_read(ci, lane >> 1);
+        const float ovr = lane_read(cr, lane_base + (lane >> 1)), ovi = lane_read(ci, lane_base + (lane >> 1));
         y0 = (lane & 1u) ? ovi : ovr;
     }
     const float d0 = discriminate_literal(Ar, Ai, Br, Bi);
@@ -1146,7 +1151,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
         // ---- the heads of the chunks that start in this segment ---------------
         // (one, in the segment's first row, unless chunks are shorter than a segment)
         if constexpr (SPAN) {
-            if (a.fused_heads != 0u) {
+            if (a.fused_heads != 0u && a.heads_packed != 0u) {
+                // every chunk that starts in the segment, sixteen lanes each, in ONE pass of chunk_head (round 3)
+                const uint32_t rpc = 1u << a.rpc_log2;
+                const uint32_t first = rb + ((rpc - ((g0 + rb) & rpc_mask)) & rpc_mask);   // the segment's first row that starts a chunk
+                const uint32_t r = first + (lane >> 4) * rpc;
+                const bool has = r < re;
+                const uint32_t rr = has ? r : rb;
+                chunk_head<COND, S16>(a, a.in + (uint64_t) rr * kRowBytes, (uint64_t) rr * kRowOutputs, lane & 15u,
+                                      has ? 4u * a.head_quads : 0u, lane & ~15u);
+            } else if (a.fused_heads != 0u) {
                 for (uint32_t r = rb; r < re; ++r)
                     if (((g0 + r) & rpc_mask) == 0u)
                         chunk_head<COND, S16>(a, a.in + (uint64_t) r * kRowBytes, (uint64_t) r * kRowOutputs, lane, 4u * a.head_quads);

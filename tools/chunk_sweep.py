@@ -13,9 +13,13 @@ for flags in (dict(), dict(lowpass_in=12500.0, lowpass_out=6500.0)):
         d = dm.Demodulator(dm.Options(buf_size=B, **flags))
         d.set_head_mode(mode)
         d.synth_fill(iq, 0, 7)
-        for _ in range(3):
+        # spin-up: after a slow, light kernel (the 256-byte case takes 6-16 ms per call) the device needs tens of
+        # milliseconds of load to be back at the clocks it holds under it; three calls were not enough (round 3: the
+        # 1-2 KiB cases read 5-10 % low)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.15:
             d.process(iq, out)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
