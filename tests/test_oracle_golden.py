@@ -355,3 +355,91 @@ def test_parity_criterion_rejects_planted_errors(orc):
     assert not parity.compare_stream(dm, opt2, g2, w2, d2).ok
     g2 = w2.copy(); g2[B // 4 + 100] -= np.float32(2 * np.pi * t2[0])           # -pi where the reference has +pi
     assert not parity.compare_stream(dm, opt2, g2, w2, d2).ok
+
+
+# ---------------------------------------------------------------------------
+# every byte pair through the three forms of the complex stencil
+# ---------------------------------------------------------------------------
+def _de_bruijn_pairs(k: int = 256) -> np.ndarray:
+    """A sequence over k symbols in which every ordered pair appears once as neighbours (de Bruijn B(k, 2), from its
+    Lyndon words), closed with its first element: 65,537 values for bytes."""
+    import sys
+    a, seq = [0] * (2 * k), []
+
+    def db(t, p):
+        if t > 2:
+            if 2 % p == 0:
+                seq.extend(a[1:p + 1])
+        else:
+            a[t] = a[t - p]
+            db(t + 1, p)
+            for j in range(a[t - p] + 1, k):
+                a[t] = j
+                db(t + 1, t)
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    db(1, 1)
+    return np.array(seq + seq[:1], dtype=np.int64)
+
+
+@pytest.mark.parametrize("kw", [dict(lowpass_in=12500.0, lowpass_out=6500.0), dict(sample_rate=96000.0, lowpass_in=12500.0, lowpass_out=6500.0),
+                                dict(lowpass_in=9600.0), dict(lowpass_in=12500.0, in_degree=4)], ids=["c3", "readme_96k", "L9600", "D4"])
+def test_every_byte_pair_through_the_stencil_forms(orc, kw):
+    """With a 2-tap complex stencil a filtered sample depends on two bytes per lane: 65,536 pairs, ALL of them here.
+    The reference's own recurrence (the restatement's filter_complex on a de Bruijn stream that holds every pair once,
+    both lanes) against float64-exact emulations of the three forms the streaming kernel has (kernels.hip:
+    plain fl(h1 x1 + fl(h0 x0 + c)); normalized h0/alpha * fl(rho X1 + X0), X = alpha (x + 128) - k exact; folded
+    fl(h1 u1 + fl(h0 u0 + C))) and against exact arithmetic, each error measured in units of the parity clause's
+    per-sample scale 2^-24 A (tests/parity.py: A = the recurrence with every coefficient replaced by its magnitude).
+      * the normalized form -- the default -- is never further from the reference than the plain form's worst pair,
+        and closer to exact arithmetic than the plain form and than the reference itself on every design;
+      * the unpack alpha * byte - k it rests on is exact for every byte (asserted in float32);
+      * the folded form's worst pair is more than twice as far (the degraded arithmetic the GPU suite catches).
+    For scale: the reference's own FMA build is 3.1-3.3 such units from its generic build at its worst pair."""
+    import demodulator_amd as dm
+    import parity
+    f32 = np.float32
+    opt = dm.Options(**kw)
+    d, din = dm.design(opt), dm.design(opt, "in")
+    h = np.asarray(din["taps"], dtype=np.float64)
+    bias, sos = float(din["bias_im"]), din["sos"]
+    assert h.size == 2 and d["stencil_form"] == "normalized"
+    c = d["normalized"]
+    alpha, kre, kim, rho = np.float64(c["alpha"]), np.float64(c["k_re"]), np.float64(c["k_im"]), np.float64(c["rho"][1])
+    x = (_de_bruijn_pairs() - 128).astype(np.float64)
+    N = x.size
+    xi = np.empty(2 * N, dtype=np.float32)
+    xi[0::2] = x
+    xi[1::2] = x
+    y = orc.filter_complex(xi, sos, pad=64)
+    K = np.arange(2 * sos.shape[0] - 1, N - 1)          # interior cells: every pair but the two or three at the stream's head
+    assert K.size >= 65532
+    ref_re, ref_im = y[0:2 * N:2].astype(np.float64)[K], y[1:2 * N:2].astype(np.float64)[K]
+    x0, x1 = x[K], x[K + 1]
+    U0, U1 = x0 + 128, x1 + 128
+    exact_re = h[0] * x0 + h[1] * x1                    # (24-bit taps times 8-bit samples: exact in float64)
+    exact_im = exact_re + bias
+
+    def rn(v):                                           # one rounding to float32 of a value float64 holds exactly
+        return f32(v).astype(np.float64)
+    plain = (rn(h[1] * x1 + rn(h[0] * x0)), rn(h[1] * x1 + rn(h[0] * x0 + bias)))
+    Xr0, Xr1, Xi0, Xi1 = alpha * U0 - kre, alpha * U1 - kre, alpha * U0 - kim, alpha * U1 - kim
+    for X in (Xr0, Xr1, Xi0, Xi1):
+        assert np.array_equal(f32(X).astype(np.float64), X)      # the unpack is exact
+    norm = (rn(rho * Xr1 + Xr0) * (h[0] / alpha), rn(rho * Xi1 + Xi0) * (h[0] / alpha))
+    Cr, Ci = np.float64(f32(-128 * (h[0] + h[1]))), np.float64(f32(bias - 128 * (h[0] + h[1])))
+    fold = (rn(h[1] * U1 + rn(h[0] * U0 + Cr)), rn(h[1] * U1 + rn(h[0] * U0 + Ci)))
+    a, a0 = parity.abs_taps(sos)
+    unit = 2.0 ** -24 * (a[0] * np.abs(x0) + a[1] * np.abs(x1) + a0)
+
+    def worst(form):
+        return max(float(np.max(np.abs(form[0] - ref_re) / unit)), float(np.max(np.abs(form[1] - ref_im) / unit)))
+
+    def off_exact(form):
+        return max(float(np.max(np.abs(form[0] - exact_re))), float(np.max(np.abs(form[1] - exact_im))))
+    w_plain, w_norm, w_fold = worst(plain), worst(norm), worst(fold)
+    print(f"{kw}: worst pair in units of 2^-24 A: plain {w_plain:.2f}, normalized {w_norm:.2f}, folded {w_fold:.2f}; "
+          f"from exact arithmetic: normalized {off_exact(norm):.2e}, plain {off_exact(plain):.2e}, reference {off_exact((ref_re, ref_im)):.2e}")
+    assert w_norm <= w_plain + 0.05
+    assert off_exact(norm) < off_exact(plain) < off_exact((ref_re, ref_im)) * 1.2
+    assert off_exact(norm) < off_exact((ref_re, ref_im))
+    assert w_fold > 2.0 * w_norm
