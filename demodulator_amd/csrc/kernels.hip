@@ -1045,14 +1045,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
         __shared__ float lds_d[kWavesPerBlock][2][64 * (kExD > 0 ? kExD : 1)];
         lds_float *wr_x[2], *wr_d[2];
         const lds_float *rd_x[2], *rd_d[2];
+        // A wavefront's two lines lie one behind the other, 128 slots in all: the slot after slot s of line p is slot
+        // (64 p + s + 1) mod 128 -- lane 63 of line 0 lands on slot 0 of line 1 and the other way round by itself, no
+        // select (v_cndmask_b32 with VCC is the slowest VALU operation this kernel had: 8.7 cycles,
+        // profiles/r1_microbench_valu_rate2.txt; round 3)
+        lds_float *const line_x = (lds_float *) &lds_x[wave][0][0];
+        lds_float *const line_d = (lds_float *) &lds_d[wave][0][0];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            wr_x[p] = (lds_float *) &lds_x[wave][p][lane * kExX];
-            wr_d[p] = (lds_float *) &lds_d[wave][p][lane * kExD];
-            rd_x[p] = lane < 63u ? (const lds_float *) &lds_x[wave][p][(lane + 1u) * kExX]
-                                 : (const lds_float *) &lds_x[wave][p ^ 1][0];
-            rd_d[p] = lane < 63u ? (const lds_float *) &lds_d[wave][p][(lane + 1u) * kExD]
-                                 : (const lds_float *) &lds_d[wave][p ^ 1][0];
+            const uint32_t own = 64u * (uint32_t) p + lane, next = (own + 1u) & 127u;
+            wr_x[p] = line_x + own * kExX;
+            wr_d[p] = line_d + own * kExD;
+            rd_x[p] = line_x + next * kExX;
+            rd_d[p] = line_d + next * kExD;
         }
         // ---- loads and waits spelled out ------------------------------------
         // hipcc keeps one vmcnt score for loads and stores together and, with
