@@ -777,6 +777,16 @@ __device__ __forceinline__ float section_update(const float (&row)[6], float cur
 // segment the heads of a segment's chunks are replayed side by side, sixteen lanes each (`chunk`, `out_index` and
 // `n_out` are then per-lane values).  The neighbour fetches shift the whole wavefront, so a head's lane 15 receives
 // the next head's lane 0: harmless where output n only reaches lanes up to n + sec_in + sec_out + 1 < 16.
+// `take` ? a : b for floats, `take` as a bit mask (all ones / zero): one v_bitop3_b32.  chunk_head's selects are all
+// of this kind (does iteration n - S - m exist for this lane's cell; is the lane odd), their masks a shift of a lane
+// expression -- where a compare and a v_cndmask_b32 on VCC cost several times a full-rate operation
+// (profiles/r1_microbench_valu_rate2.txt).
+__device__ __forceinline__ float pick(uint32_t take, float a, float b) {
+    return __uint_as_float(bit_select(take, __float_as_uint(a), __float_as_uint(b)));
+}
+// all ones where v >= 0
+__device__ __forceinline__ uint32_t nonneg(int v) { return ~(uint32_t) (v >> 31); }
+
 template <int COND, bool S16, int MAXSEC = kFusedSections, class LAUNCH = RowLaunch, bool PRE = false>
 __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk, uint64_t out_index, uint32_t lane, uint32_t n_out,
                                            uint32_t lane_base = 0u) {
@@ -808,10 +818,10 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
                     const float vAi = section_update<false>(a.sos_pre[m], cAi, pBi, x0i, x1i);
                     const float vBr = section_update<true>(a.sos_pre[m], cBr, nBr, x1r, x2r);
                     const float vBi = section_update<false>(a.sos_pre[m], cBi, nBi, x1i, x2i);
-                    const bool exA = cellA - Sp - m >= 0, exB = cellA + 1 - Sp - m >= 0;
+                    const uint32_t exA = nonneg(cellA - Sp - m), exB = nonneg(cellA + 1 - Sp - m);
                     pAr = cAr; pAi = cAi; pBr = cBr; pBi = cBi;
-                    cAr = exA ? vAr : cAr; cAi = exA ? vAi : cAi;
-                    cBr = exB ? vBr : cBr; cBi = exB ? vBi : cBi;
+                    cAr = pick(exA, vAr, cAr); cAi = pick(exA, vAi, cAi);
+                    cBr = pick(exB, vBr, cBr); cBi = pick(exB, vBi, cBi);
                 }
             }
             u0r = cAr; u0i = cAi; u1r = cBr; u1i = cBi;
@@ -852,10 +862,10 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
                 const float vAi = section_update<false>(a.sos_in[m], cAi, pBi, u0i, u1i);
                 const float vBr = section_update<true>(a.sos_in[m], cBr, nBr, u1r, u2r);
                 const float vBi = section_update<false>(a.sos_in[m], cBi, nBi, u1i, u2i);
-                const bool exA = cellA - Si - m >= 0, exB = cellA + 1 - Si - m >= 0;
+                const uint32_t exA = nonneg(cellA - Si - m), exB = nonneg(cellA + 1 - Si - m);
                 pAr = cAr; pAi = cAi; pBr = cBr; pBi = cBi;
-                cAr = exA ? vAr : cAr; cAi = exA ? vAi : cAi;
-                cBr = exB ? vBr : cBr; cBi = exB ? vBi : cBi;
+                cAr = pick(exA, vAr, cAr); cAi = pick(exA, vAi, cAi);
+                cBr = pick(exB, vBr, cBr); cBi = pick(exB, vBi, cBi);
             }
         }
         Ar = cAr; Ai = cAi; Br = cBr; Bi = cBi;
@@ -866,9 +876,9 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
         const uint32_t s0 = lane >> 1, s1 = (lane + 1u) >> 1;
         const float rA0 = lane_read(Ar, lane_base + s0), rB0 = lane_read(Br, lane_base + s0), iA0 = lane_read(Ai, lane_base + s0), iB0 = lane_read(Bi, lane_base + s0);
         const float rA1 = lane_read(Ar, lane_base + s1), rB1 = lane_read(Br, lane_base + s1), iA1 = lane_read(Ai, lane_base + s1), iB1 = lane_read(Bi, lane_base + s1);
-        const bool own = a.in_separate == 0;
-        const float ztr = own ? ((lane & 1u) ? rB0 : rA0) : 0.f, zti = own ? ((lane & 1u) ? iB0 : iA0) : 0.f;
-        const float zur = own ? ((lane & 1u) ? rA1 : rB1) : 0.f, zui = own ? ((lane & 1u) ? iA1 : iB1) : 0.f;
+        const uint32_t own = a.in_separate == 0 ? ~0u : 0u, odd = 0u - (lane & 1u);
+        const float ztr = __uint_as_float(own & __float_as_uint(pick(odd, rB0, rA0))), zti = __uint_as_float(own & __float_as_uint(pick(odd, iB0, iA0)));
+        const float zur = __uint_as_float(own & __float_as_uint(pick(odd, rA1, rB1))), zui = __uint_as_float(own & __float_as_uint(pick(odd, iA1, iB1)));
         float cr = 0.f, ci = 0.f, pr = 0.f, pi = 0.f;
 #pragma unroll
         for (int m = MAXSEC - 1; m >= 0; --m) {
@@ -876,14 +886,14 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
                 const float nr = from_next_lane(pr, 0.f), ni = from_next_lane(pi, 0.f);
                 const float vr = section_update<true>(a.sos_in[m], cr, nr, ztr, zur);
                 const float vi = section_update<false>(a.sos_in[m], ci, ni, zti, zui);
-                const bool ex = (int) lane <= m + Si - 1;  // iteration K - 2 Si + 1 + (t - 1 + Si - m) is one of the last 2 Si - 1
+                const uint32_t ex = nonneg(m + Si - 1 - (int) lane);  // iteration K - 2 Si + 1 + (t - 1 + Si - m) is one of the last 2 Si - 1
                 pr = cr; pi = ci;
-                cr = ex ? vr : cr; ci = ex ? vi : ci;
+                cr = pick(ex, vr, cr); ci = pick(ex, vi, ci);
             }
         }
         // output cell n starts from overflow cell n / 2: its real part (n even) or imaginary part (n odd)
         const float ovr = lane_read(cr, lane_base + (lane >> 1)), ovi = lane_read(ci, lane_base + (lane >> 1));
-        y0 = (lane & 1u) ? ovi : ovr;
+        y0 = pick(0u - (lane & 1u), ovi, ovr);
     }
     const float d0 = discriminate_literal(Ar, Ai, Br, Bi);
     const float d1 = from_next_lane(d0, 0.f);
@@ -893,9 +903,9 @@ __device__ __forceinline__ void chunk_head(const LAUNCH &a, const uint8_t *chunk
         if (m < So) {
             const float ny = from_next_lane(py, 0.f);
             const float v = section_update<true>(a.sos_out[m], cy, ny, d0, d1);
-            const bool ex = (int) lane - So - m >= 0;
+            const uint32_t ex = nonneg((int) lane - So - m);
             py = cy;
-            cy = ex ? v : cy;
+            cy = pick(ex, v, cy);
         }
     }
     if (lane < n_out) {
