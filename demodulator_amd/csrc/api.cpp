@@ -808,7 +808,7 @@ int demod_design_normalized_constants(const demod_params *p, float *alpha, float
     if (k_im) *k_im = plan.norm_k_im;
     const int n = plan.stencil_in.taps;
     for (int j = 0; rho && j < n && j < max_taps; ++j) rho[j] = plan.rho[j];
-    return plan.norm_ok ? n : 0;
+    return n;
 }
 
 int demod_synth_fill(demod_ctx *ctx, void *d_dst, uint64_t first_byte, uint64_t n_bytes, uint64_t seed,

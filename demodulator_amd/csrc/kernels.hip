@@ -72,7 +72,36 @@ constexpr int kWavesPerBlock = DEMOD_WAVES_PER_BLOCK;  // independent wavefronts
 #ifndef DEMOD_ROWS_PER_WAVE
 #define DEMOD_ROWS_PER_WAVE 4
 #endif
-constexpr int kGroup = DEMOD_ROWS_PER_WAVE;  // rows (1 KiB each) one wavefront owns and keeps in flight
+constexpr int kGroup = DEMOD_ROWS_PER_WAVE;  // rows (1 KiB each) of a segment: what one wavefront owns
+// Rows a wavefront keeps in flight: a segment's first kFlight rows are asked for up front, row k + kFlight when row k
+// has been computed and stored (into the registers row k's bytes arrived in).  kFlight == kGroup: everything up front.
+#ifndef DEMOD_LOADS_IN_FLIGHT
+#define DEMOD_LOADS_IN_FLIGHT (DEMOD_ROWS_PER_WAVE < 4 ? DEMOD_ROWS_PER_WAVE : 4)
+#endif
+constexpr int kFlight = DEMOD_LOADS_IN_FLIGHT;
+static_assert(kFlight >= 1 && kFlight <= kGroup && kGroup <= 8, "segment shape");
+// Vector-memory operations issued after row k's load and before row k is needed (loads and stores retire in issue
+// order: waiting until only that many are outstanding is waiting for row k's bytes and for nothing younger).  The
+// sequence is: look-ahead load, loads of rows 0 .. kFlight-1, then per row k: [wait] compute, store k, load k + kFlight
+// (while there is one).
+constexpr int younger_than_row(int k) {
+    int n = 0;
+    if (k < kFlight) {
+        n = kFlight - 1 - k;
+        for (int j = 0; j < k; ++j) n += 1 + (j + kFlight < kGroup ? 1 : 0);
+    } else {
+        for (int j = k - kFlight + 1; j < k; ++j) n += 1 + (j + kFlight < kGroup ? 1 : 0);
+    }
+    return n;
+}
+// 16 bytes per lane of a row: scalar base + this lane's offset (issued from inline asm, invisible to hipcc's own wait counting)
+__device__ __forceinline__ void ask_row(u32x4 &q, uint32_t lane_off, const uint8_t *row) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" DEMOD_LOAD_POLICY : "=v"(q) : "v"(lane_off), "s"(row) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(u32x4 &q) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q) : "i"(N) : "memory");
+}
 
 
 // ---------------------------------------------------------------------------
@@ -1077,9 +1106,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
         // in flight, so the loads are issued from inline asm (invisible to
         // hipcc) and waited for by count: gfx950 retires vector-memory
         // operations in issue order, and when row k is needed exactly
-        // kGroup-1-k younger loads and k stores have been issued after its
-        // load -- kGroup-1 operations for every k.  Requirements kept below:
-        // always kGroup + 1 loads (a clipped segment asks for row rb again in
+        // kFlight-1-k younger loads and k stores have been issued after its
+        // load -- kFlight-1 operations for every k when the whole segment is asked for up front
+        // (kFlight == kGroup), younger_than_row(k) in general.  Requirements kept below:
+        // always the same loads (a clipped segment asks for row rb again in
         // place of the rows it lacks; those are never computed, only waited for
         // at the end), exactly one store per computed row, nothing else that
         // touches vector memory before the last row is stored, wait statements
@@ -1105,18 +1135,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
             if constexpr (nx > 4) asm volatile("global_load_dwordx4 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn4) : "v"(np) : "memory");
             else if constexpr (nx > 2) asm volatile("global_load_dwordx2 %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn2) : "v"(np) : "memory");
             else asm volatile("global_load_dword %0, %1, off" DEMOD_LOAD_POLICY : "=v"(qn1) : "v"(np) : "memory");
-            u32x4 qa[kGroup];
-#pragma unroll
-            for (int k = 0; k < kGroup; ++k) {
+            u32x4 qa[kFlight];
+            // row k of the segment (counted from its end); a clipped segment asks for row rb in place of the rows it lacks
+            auto row_at = [&](int k) -> const uint8_t * {
                 const uint32_t row = (FULL || re >= rb + 1u + (uint32_t) k) ? re - 1u - (uint32_t) k : rb;
-                const uint8_t *rp = a.in + (uint64_t) row * kRowBytes;
-                asm volatile("global_load_dwordx4 %0, %1, %2" DEMOD_LOAD_POLICY : "=v"(qa[k]) : "v"(lane_in), "s"(rp) : "memory");
-            }
+                return a.in + (uint64_t) row * kRowBytes;
+            };
+#pragma unroll
+            for (int k = 0; k < kFlight; ++k) ask_row(qa[k], lane_in, row_at(k));
             __builtin_amdgcn_sched_barrier(0);
-            // the look-ahead row was asked for first: kGroup younger loads may stay in flight
-            if constexpr (nx > 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn4) : "i"(kGroup) : "memory");
-            else if constexpr (nx > 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn2) : "i"(kGroup) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn1) : "i"(kGroup) : "memory");
+            // the look-ahead row was asked for first: kFlight younger loads may stay in flight
+            if constexpr (nx > 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn4) : "i"(kFlight) : "memory");
+            else if constexpr (nx > 2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn2) : "i"(kFlight) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qn1) : "i"(kFlight) : "memory");
             {
                 uint4 qn = make_uint4(0, 0, 0, 0);
                 if constexpr (nx > 4) qn = make_uint4(qn4.x, qn4.y, qn4.z, qn4.w);
@@ -1145,20 +1176,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
                     if (re < rb + 1u + (uint32_t) k) break;
                 }
                 const uint32_t r = re - 1u - (uint32_t) k;
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(qa[k]) : "i"(kGroup - 1) : "memory");
+                u32x4 &q = qa[k % kFlight];
+                switch (k) {   // (k is a constant once the loop is unrolled: one wait statement survives)
+                case 0: wait_vm<younger_than_row(0)>(q); break;
+                case 1: wait_vm<younger_than_row(1)>(q); break;
+                case 2: wait_vm<younger_than_row(2)>(q); break;
+                case 3: wait_vm<younger_than_row(3)>(q); break;
+                case 4: wait_vm<younger_than_row(4)>(q); break;
+                case 5: wait_vm<younger_than_row(5)>(q); break;
+                case 6: wait_vm<younger_than_row(6)>(q); break;
+                default: wait_vm<younger_than_row(7)>(q); break;
+                }
                 float y[4];
                 LdsExchange ex{wr_x[k & 1], rd_x[k & 1], wr_d[k & 1], rd_d[k & 1],
                                SPAN && lane == 0u && ((g0 + r) & rpc_mask) == 0u, past_re, past_im};
-                process_row<TIN, TOUT, COND, false>(make_uint4(qa[k].x, qa[k].y, qa[k].z, qa[k].w), a, ex, 16, lead, y);
+                process_row<TIN, TOUT, COND, false>(make_uint4(q.x, q.y, q.z, q.w), a, ex, 16, lead, y);
                 // (the first lanes of a chunk's first row hold interior-formula values for
                 // outputs that are not interior: chunk_head / demod_heads overwrites them)
                 store_row<S16, TIN == 0>(out_address<S16>(a.out, (uint64_t) r * kRowOutputs), lane_out, y, a.out_scale);
+                if (k + kFlight < kGroup) ask_row(q, lane_in, row_at(k + kFlight));   // into the registers this row's bytes arrived in
             }
             if constexpr (!FULL) {
                 // the stand-in loads of the missing rows land in registers hipcc believes free
                 // from here on: wait for them before anything else runs
 #pragma unroll
-                for (int k = 0; k < kGroup; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa[k]) : : "memory");
+                for (int k = 0; k < kFlight; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa[k]) : : "memory");
             }
         };
         if (re - rb == (uint32_t) kGroup) segment(std::true_type{});
@@ -1170,11 +1212,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (S16 || SPAN) ? DEMOD_MIN_WAVE
                 // every chunk that starts in the segment, sixteen lanes each, in ONE pass of chunk_head (round 3)
                 const uint32_t rpc = 1u << a.rpc_log2;
                 const uint32_t first = rb + ((rpc - ((g0 + rb) & rpc_mask)) & rpc_mask);   // the segment's first row that starts a chunk
-                const uint32_t r = first + (lane >> 4) * rpc;
-                const bool has = r < re;
-                const uint32_t rr = has ? r : rb;
-                chunk_head<COND, S16>(a, a.in + (uint64_t) rr * kRowBytes, (uint64_t) rr * kRowOutputs, lane & 15u,
-                                      has ? 4u * a.head_quads : 0u, lane & ~15u);
+                for (uint32_t pass = 0; first + 4u * pass * rpc < re; ++pass) {   // four heads per pass
+                    const uint32_t r = first + (4u * pass + (lane >> 4)) * rpc;
+                    const bool has = r < re;
+                    const uint32_t rr = has ? r : rb;
+                    chunk_head<COND, S16>(a, a.in + (uint64_t) rr * kRowBytes, (uint64_t) rr * kRowOutputs, lane & 15u,
+                                          has ? 4u * a.head_quads : 0u, lane & ~15u);
+                }
             } else if (a.fused_heads != 0u) {
                 for (uint32_t r = rb; r < re; ++r)
                     if (((g0 + r) & rpc_mask) == 0u)

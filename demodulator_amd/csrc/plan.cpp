@@ -223,7 +223,8 @@ double plan_magnitude_bound(const Plan &pl) {
 //       normalised  the taps it applies, sum_j |h0 rho_j - h_j| 128, and its own partial sums
 //                   alpha (x + s) + sum_{i<=j} rho_i alpha (x + s), 1 <= j < T - 1, times |h0| / alpha
 // The normalised form is allowed where the bias it applies is within half an ulp of the bias (as a float of
-// that size), its price is not above the plain form's, and the discriminator's products stay far from overflow.
+// that size), its price is at most an eighth of the plain form's (see below), and the discriminator's products stay
+// far from overflow.
 static double half_ulp(double magnitude) {
     if (!(magnitude > 0)) return 0;
     int e;
@@ -292,7 +293,13 @@ static void price_normalised_stencil(Plan &plan) {
     const double zmax = alpha * (128.0 + std::fabs((double) s)) * (double) rho_abs;
     plan.norm_error = norm;
     plan.plain_error = plain;
-    plan.norm_ok = plan.norm_bias_error <= half_ulp(std::fabs((double) st.bias_im)) && norm <= plain && 2.0 * zmax * zmax < 1e30;
+    // "Not above the plain form's" is not enough: the taps' error is the same at every sample with the same bytes,
+    // where the plain form's roundings scatter, and inputs can be SEARCHED for which it is what remains (round 3:
+    // tools/adversarial_sweep.py 1000 7 found a Chebyshev -D 2 design, price 3.6e-6 against 7.6e-6, with 3 outputs
+    // between the criterion's bounds where the plain form has none).  An eighth of the plain form's price keeps the
+    // form to designs whose quotients h_j / h_0 happen to be floats to a few percent of an ulp -- BASELINE config 3 /
+    // the target: 4.4e-8 against 7.6e-6 -- and hands every other design to the plain form.
+    plan.norm_ok = plan.norm_bias_error <= half_ulp(std::fabs((double) st.bias_im)) && 8.0 * norm <= plain && 2.0 * zmax * zmax < 1e30;
 }
 
 bool build_plan(const Options &o, Plan &plan, std::string &err) {

@@ -295,8 +295,8 @@ int demod_design_unpack_folded(const demod_params *p);
 int demod_set_unpack_fold(demod_ctx *ctx, int on);
 /* The NORMALIZED form's constants for an option set (host only; what the tests check the exactness claims on):
  * the unpack X = alpha * (sample + 128) - (k_re, k_im) and the taps rho[j] = h[j] / h[0] (rho[0] = 1).  Returns
- * the number of taps when the form is available for the design, 0 when it is not (the values are then what the
- * search found, for inspection), negative on error. */
+ * the number of taps of the complex stencil (0: no complex stage), negative on error; whether the form is OFFERED for
+ * the design is demod_design_stencil_form's answer (the constants are what the search found either way). */
 int demod_design_normalized_constants(const demod_params *p, float *alpha, float *k_re, float *k_im, float *rho, int max_taps);
 
 /* Seamless mode (not reference behaviour; off by default): the whole stream is

@@ -200,8 +200,8 @@ def test_normalized_stencil_constants_are_exact_where_the_form_is_offered():
       * alpha has 16 significant bits and k_re = 128 alpha exactly: the real lane is alpha * x to the bit;
       * alpha * U - k_im is a float for EVERY byte value U (no rounding in the unpack), and below 2^8;
       * the bias this applies, h0 (1 + sum rho) (128 - k_im / alpha), is the design's to within half an ulp of it;
-      * the taps h0 rho_j are the design's to within what build_plan reports (normalized_error), which is not above
-        what the plain form's intermediate rounding can do (plain_error);
+      * the taps h0 rho_j are the design's to within what build_plan reports (normalized_error), which is at most an
+        eighth of what the plain form's intermediate rounding can do (plain_error);
     and the form is never offered for -q2 or without a complex stage.  BASELINE config 3 / the target has it."""
     from fractions import Fraction as F
 
@@ -227,8 +227,8 @@ def test_normalized_stencil_constants_are_exact_where_the_form_is_offered():
         ulp = F(2) ** (int(np.floor(np.log2(abs(float(bias))))) - 23)
         assert abs(applied - bias) <= ulp / 2, (opt, float(applied - bias))
         taps_err = sum(abs(h[0] * r - hj) for r, hj in zip(rho, h)) * 128
-        # (normalized_error as reported includes the bias term bounded above)
-        assert float(taps_err) <= d["normalized_error"] + 1e-12 and d["normalized_error"] <= d["plain_error"] + float(ulp / 2), opt
+        # (normalized_error as reported includes the bias term bounded above; offered at an eighth of the plain form's price)
+        assert float(taps_err) <= d["normalized_error"] + 1e-12 and 8 * d["normalized_error"] <= d["plain_error"] + 8 * float(ulp / 2), opt
 
     L = dict(lowpass_in=12500.0, lowpass_out=6500.0)
     assert dm.design(dm.Options(**L))["stencil_form"] == "normalized"
@@ -248,7 +248,7 @@ def test_normalized_stencil_constants_are_exact_where_the_form_is_offered():
         if d["stencil_form"] == "normalized":
             offered += 1
             check(opt)
-    assert offered > 50
+    assert offered > 8      # (about one design in six has quotients that close to floats)
 
 
 def test_every_accepted_design_is_proven_finite():
