@@ -159,6 +159,10 @@ int demod_output_bytes(const demod_ctx *ctx) { return ctx ? (int) ctx->out_bytes
 
 int demod_set_seamless(demod_ctx *ctx, int on) {
     if (!ctx) return DEMOD_E_INVAL;
+    if ((on != 0) != ctx->seamless && (host_pipe_busy(ctx) || ctx->rings)) {
+        ctx->fail(DEMOD_E_INVAL, "seamless mode cannot change while submitted pieces are uncollected or a ring is open");
+        return DEMOD_E_INVAL;
+    }
     ctx->seamless = on != 0;
     return DEMOD_OK;
 }
@@ -169,6 +173,10 @@ int demod_set_stencil_form(demod_ctx *ctx, int form) {
     if (!ctx) return DEMOD_E_INVAL;
     if (form != DEMOD_STENCIL_AUTO && form != DEMOD_STENCIL_PLAIN && form != DEMOD_STENCIL_FOLDED && form != DEMOD_STENCIL_NORMALIZED) {
         ctx->fail(DEMOD_E_INVAL, "stencil form must be DEMOD_STENCIL_AUTO, _PLAIN, _FOLDED or _NORMALIZED");
+        return DEMOD_E_INVAL;
+    }
+    if (form != ctx->stencil_form && (host_pipe_busy(ctx) || ctx->rings)) {
+        ctx->fail(DEMOD_E_INVAL, "the stencil form cannot change while submitted pieces are uncollected or a ring is open");
         return DEMOD_E_INVAL;
     }
     ctx->stencil_form = form;
@@ -607,6 +615,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
                 if (ragged || p1 < split) a.halo = nullptr;  // only the buffer's last rows can need the shard halo
                 if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, rows_conditioning(ctx), stream)) {
                     ctx->fail(DEMOD_E_HIP, "demod_rows launch", hipGetLastError());
+                    if (ev.first) ctx->event_pool.push_back(ev);   // (the timing pair goes back where it came from)
                     return DEMOD_E_HIP;
                 }
                 ++ctx->last_row_launches;
@@ -624,6 +633,7 @@ int demod_process_device(demod_ctx *ctx, const void *d_in_v, uint64_t n_bytes, v
             a.halo = nullptr;
             if (launch_rows(a, pl.stencil_in.taps, pl.out.taps, rows_conditioning(ctx), stream)) {
                 ctx->fail(DEMOD_E_HIP, "demod_rows (ragged) launch", hipGetLastError());
+                if (ev.first) ctx->event_pool.push_back(ev);
                 return DEMOD_E_HIP;
             }
             ++ctx->last_row_launches;

@@ -284,7 +284,9 @@ double demod_design_magnitude_bound(const demod_params *p);
  * demod_design_stencil_form which one AUTO gives an option set (and the two error bounds, in the
  * reference's units of a filtered sample; host only).  demod_design_unpack_folded: 1 when FOLDED is
  * available.  demod_set_unpack_fold(ctx, on) = demod_set_stencil_form(ctx, on ? FOLDED : AUTO).
- * There is no environment switch: the arithmetic of a context changes only through these calls. */
+ * There is no environment switch: the arithmetic of a context changes only through these calls -- and not in the
+ * middle of a stream: a change of form (like one of the output format or of seamless mode) is refused with
+ * DEMOD_E_INVAL while submitted pieces are uncollected or a ring is open. */
 #define DEMOD_STENCIL_AUTO 0
 #define DEMOD_STENCIL_PLAIN 1
 #define DEMOD_STENCIL_FOLDED 2

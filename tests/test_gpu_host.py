@@ -106,6 +106,17 @@ def test_ring_misuse_is_reported():
                 ring.put(np.zeros(4096, np.uint8))                   # after the end
             with pytest.raises(dm.DemodError, match="ring is open"):
                 d.set_output_format("s16", 1.0)
+            # ... and so is everything else that would change the results of a stream under way
+            with pytest.raises(dm.DemodError, match="ring is open"):
+                d.set_seamless(True)
+            d.set_seamless(False)                                    # (no change: accepted)
+    with dm.Demodulator(dm.Options(buf_size=4096, lowpass_in=12500.0, lowpass_out=6500.0)) as d:
+        with d.ring():
+            with pytest.raises(dm.DemodError, match="ring is open"):
+                d.set_stencil_form("plain")
+            d.set_stencil_form("auto")
+        d.set_stencil_form("plain")                                  # the ring is closed: accepted
+        assert d.stencil_form == "plain"
     with dm.Demodulator(dm.Options(buf_size=64)) as d:
         with pytest.raises(dm.DemodError, match="1 KiB"):
             d.ring()
