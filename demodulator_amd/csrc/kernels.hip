@@ -1933,9 +1933,11 @@ int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
             }
         }
     }
+    // 4 taps either side: what -L gives degrees 10-13 (the reference's -D follows -d, src/main.c:193)
+    if (tin == 4 && tout == 4) return launch_rows_t<4, 4, COND>(a, s);
     // zero-padded taps make the long stencils exact for any shorter design
     if constexpr (COND != kShiftOriginNorm) {
-        if (tin == 0) return launch_rows_t<0, kMaxTaps, COND>(a, s);
+        if (tin == 0) return tout == 4 ? launch_rows_t<0, 4, COND>(a, s) : launch_rows_t<0, kMaxTaps, COND>(a, s);
     }
     return launch_rows_t<kMaxTaps, kMaxTaps, COND>(a, s);
 #endif

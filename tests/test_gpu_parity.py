@@ -452,6 +452,31 @@ def test_random_option_sets_and_lengths(orc):
     assert n_cases >= min(30, rounds // 2)
 
 
+@pytest.mark.parametrize("kw,taps", [
+    (dict(lowpass_in=12500.0, lowpass_out=6500.0, in_degree=12, out_degree=12), (4, 4)),
+    (dict(lowpass_in=9600.0, in_degree=10, out_degree=13, sample_rate=96000.0), (4, 4)),
+    (dict(out_degree=12), (0, 4)),
+    (dict(out_degree=11, mode=0x18), (2, 4)),       # -q2 puts its 2-tap highpass in front: the zero-padded 5-tap build
+], ids=["D12d12", "D10d13_96k", "d12", "q2_d11"])
+def test_four_tap_designs(orc, kw, taps):
+    """Degrees 10-13 give 4-tap look-ahead stencils; with -L the reference's input degree follows the output degree
+    (src/main.c:193), so 4 taps on both sides -- and 4 on the output side alone -- have builds of their own (round 3);
+    every other combination runs the zero-padded 5-tap build.  Same results either way: the oracle's."""
+    for B in (16384, 1024):
+        opt = dm.Options(buf_size=B, **kw)
+        data = oracle.synth_bytes(0x44 + B, 0, 37 * B + 2 * 1024 + 36)
+        want = orc.process(oracle.Flags(**opt.__dict__), data)
+        with dm.Demodulator(opt) as d:
+            assert (len(d.taps("in")[0]), len(d.taps("out")[0])) == taps
+            for form in ("auto", "plain"):
+                d.set_stencil_form(form)
+                got = d.process_host(data)
+                _check(f"4-tap {kw} B={B} {form}", got, want, opt, data)
+            d.set_output_format("s16", 0.02)
+            got16 = d.process_host(data)
+        assert np.array_equal(got16, _s16_model(got, 0.02))        # the int16 builds: the same values, converted
+
+
 def test_ill_conditioned_sample_of_a_design_whose_folded_constant_is_inexact(orc):
     """-L 9600 at 125 kS/s: taps 2.0430384, -0.6233514, whose folded unpack constant -128 * sum(h)
     is half an ulp away from its float (7.6e-6).  Samples (18, -10), (59, -36) filter to
