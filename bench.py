@@ -14,6 +14,8 @@ Workloads (BASELINE.json / SURVEY.md section 8d):
     c2      2^30 samples per GPU, no -L, default -l  (configs[1])
     c4      2^31 samples per GPU of one sharded stream (configs[3]: 2^34 at 8 GPUs)
     c5      32 channels x 2^24 samples per GPU, batched (configs[4]: 256 channels at 8 GPUs)
+  (beside the default line, under "also": c3, c2, c3 with int16 output, the other forms of the complex stencil, and c3 on a
+   smooth FM-like signal -- the kernel's clock is power-managed and the prescribed random bytes are its most expensive input)
 
 For N > 1 there is one process per GPU: either the driver launches them with
 torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
@@ -85,6 +87,10 @@ WORKLOADS = {
                      desc="C3 with the plain form of the complex stencil (round 2's default): 2^30 samples, -L 12500 -l 6500"),
     # not the default arithmetic: the unpack's -128 folded into the complex stencil's constant
     # (faster than plain, but outside the parity criterion at samples that filter to next to nothing: DESIGN.md section 5)
+    # not the prescribed synthetic input: the same C3 run on a smooth FM-like signal (what an SDR delivers).  The -L kernel's
+    # clock is power-managed and random bytes toggle the most bits: this line shows what the prescribed input costs
+    "c3_fm": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, signal="fm",
+                  desc="C3 on a smooth FM-like signal instead of uniformly random bytes (same kernel, same sizes): 2^30 samples, -L 12500 -l 6500"),
     "c3_fold": dict(log2_samples=30, flags=dict(lowpass_in=12500.0, lowpass_out=6500.0), seed=0xD3300D03, form="folded",
                     desc="C3 with the optional folded unpack (not the default arithmetic): 2^30 samples, -L 12500 -l 6500"),
 }
@@ -157,7 +163,19 @@ def run_workload(dm, torch, dist, name: str, steps: int, warmup: int, rank: int,
     # interleave moves the kernel time by up to 7 % on some devices of the pool and not at
     # all on others: tools/skew_probe.py, profiles/r1_buffer_placement.txt.)
     out = torch.empty(n_bytes // 4, dtype=torch.int16 if s16 else torch.float32, device=dev)
-    d.synth_fill(iq, me.start, wl["seed"])  # this rank's bytes of the global stream
+    if wl.get("signal") == "fm":
+        # 127.5 + 100 cos/sin(phase), phase = a carrier plus a slow tone's integral (SURVEY.md section 8d's secondary input), one
+        # 2 MiB period repeated
+        import numpy as np
+        m = 1 << 20
+        t = np.arange(m, dtype=np.float64)
+        ph = 2 * np.pi * (0.05 * t + 40.0 * np.sin(2 * np.pi * t / 4096.0))
+        period = np.empty(2 * m, dtype=np.uint8)
+        period[0::2] = np.clip(np.rint(127.5 + 100.0 * np.cos(ph)), 0, 255)
+        period[1::2] = np.clip(np.rint(127.5 + 100.0 * np.sin(ph)), 0, 255)
+        iq.copy_(torch.from_numpy(period).to(dev).repeat(n_bytes // (2 * m)))
+    else:
+        d.synth_fill(iq, me.start, wl["seed"])  # this rank's bytes of the global stream
     halo = torch.zeros(dm.HALO_BYTES, dtype=torch.uint8, device=dev)
 
     def exchange():
@@ -538,7 +556,7 @@ def main() -> int:
 
         if world == 1 and not args.no_extra:
             also = {}
-            for name in ("c3", "c2", "c3_s16", "c3_plain", "c3_fold"):
+            for name in ("c3", "c2", "c3_s16", "c3_plain", "c3_fold", "c3_fm"):
                 if name == args.workload:
                     continue
                 bps = 3 if WORKLOADS[name].get("out") == "s16" else ALGO_BYTES_PER_SAMPLE
