@@ -1933,7 +1933,7 @@ int launch_rows_c(const RowLaunch &a, int tin, int tout, hipStream_t s) {
             }
         }
     }
-    // 4 taps either side: what -L gives degrees 10-13 (the reference's -D follows -d, src/main.c:193)
+    // 4 taps either side: what -L gives degrees 10-13 (without -D the input filter takes the output filter's degree, src/matrix.c:190-192)
     if (tin == 4 && tout == 4) return launch_rows_t<4, 4, COND>(a, s);
     // zero-padded taps make the long stencils exact for any shorter design
     if constexpr (COND != kShiftOriginNorm) {

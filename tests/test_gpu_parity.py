@@ -459,8 +459,8 @@ def test_random_option_sets_and_lengths(orc):
     (dict(out_degree=11, mode=0x18), (2, 4)),       # -q2 puts its 2-tap highpass in front: the zero-padded 5-tap build
 ], ids=["D12d12", "D10d13_96k", "d12", "q2_d11"])
 def test_four_tap_designs(orc, kw, taps):
-    """Degrees 10-13 give 4-tap look-ahead stencils; with -L the reference's input degree follows the output degree
-    (src/main.c:193), so 4 taps on both sides -- and 4 on the output side alone -- have builds of their own (round 3);
+    """Degrees 10-13 give 4-tap look-ahead stencils; with -L and no -D the reference's input filter takes the output filter's
+    degree (src/matrix.c:190-192), so 4 taps on both sides -- and 4 on the output side alone -- have builds of their own (round 3);
     every other combination runs the zero-padded 5-tap build.  Same results either way: the oracle's."""
     for B in (16384, 1024):
         opt = dm.Options(buf_size=B, **kw)
